@@ -1,0 +1,355 @@
+"""CPU oracle for the MRFP+ training hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+Nothing under ``mrfp_amd/`` imports it, and the product path raises when the HIP
+library is missing instead of falling back to anything here.
+
+It is a from-scratch, purely functional restatement (stock PyTorch fp32 ops on the
+CPU, no ``nn.Module``) of the arithmetic of the reference model
+``MRFPPlus`` (reference ``deepv3.py:152-367``) and of its callees:
+
+* ResNet-50 7x7-stem trunk with the ``iw`` InstanceNorm taps
+  (reference ``network/Resnet.py:148-227, 514-585``),
+* ASPP (reference ``deepv3.py:64-126``), decoder (``deepv3.py:200-219, 347-361``),
+* HRFP random over-complete branch (``deepv3.py:221-254, 320-330, 355-357``),
+* NP+ (``deepv3.py:268-277``),
+* the CE(ignore 255) criterion, SGD + poly-LR train step (``main.py:822-839, 857-864``),
+* the eval histogram / mIoU arithmetic (``metrics.py:60-85, 122-126``).
+
+Unlike the reference, every random quantity is an explicit argument (the three
+Bernoulli toggles, the NP+ normal draws, the HRFP weights live in the state dict), so
+that a GPU implementation with a different RNG can be compared on identical numbers.
+
+Parity pin: ``tests/golden/make_golden.py`` (run in the build container, where the
+reference is importable) proves this restatement equal to the reference module on the
+same weights / inputs / RNG stream and writes the committed fixtures
+``tests/golden/*.npz`` that ``tests/test_oracle_golden.py`` re-checks everywhere.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# ResNet-50 stage table: (name, planes, blocks, stride of first block)
+R50_STAGES = (("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2), ("layer4", 512, 3, 2))
+
+# HRFP stage table (reference deepv3.py:221-237 and 320-327):
+#   (conv key, bn key, dilation, resize kind, resize argument)
+# resize kind 'scale' -> F.interpolate(scale_factor=s) ; 'half' -> size=(int(h/2),int(w/2)) ;
+# 'quarter' -> size=(ceil(h/4),ceil(w/4)) where h,w are the *network input* size.
+HRFP_STAGES = (
+    ("OClayer1", "OC1_bn", 1, "scale", 1.205),
+    ("OClayer2", "OC2_bn", 1, "scale", 1.2),
+    ("OClayer3", "OC3_bn", 2, "scale", 1.2),
+    ("OClayer4", "OC4_bn", 2, "half", None),
+    ("OCdeclayer1", "OC1_decbn", 1, "half", None),
+    ("OCdeclayer2", "OC2_decbn", 1, "scale", 0.838),
+    ("OCdeclayer3", "OC3_decbn", 2, "scale", 0.798),
+    ("OCdeclayer4", "OC4_decbn", 2, "quarter", None),
+)
+
+
+# --------------------------------------------------------------------------------------
+# elementary ops
+# --------------------------------------------------------------------------------------
+def batch_norm(sd: Dict[str, Tensor], key: str, x: Tensor, train: bool,
+               new_stats: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """BatchNorm2d as the reference's Norm2d/SyncBatchNorm behaves on one process
+    (reference mynn.py:19-25, config.py:93): batch statistics (biased variance) in train
+    mode, running statistics in eval mode.  If ``new_stats`` is given, the updated running
+    buffers (momentum 0.1, unbiased variance) are written there instead of in place."""
+    w, b = sd[key + ".weight"], sd[key + ".bias"]
+    rm, rv = sd[key + ".running_mean"], sd[key + ".running_var"]
+    if not train:
+        return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
+    if new_stats is not None:
+        rm, rv = rm.clone(), rv.clone()
+        new_stats[key + ".running_mean"], new_stats[key + ".running_var"] = rm, rv
+        out = F.batch_norm(x, rm, rv, w, b, True, BN_MOMENTUM, BN_EPS)
+        return out
+    return F.batch_norm(x, None, None, w, b, True, BN_MOMENTUM, BN_EPS)
+
+
+def instance_norm(sd: Dict[str, Tensor], key: str, x: Tensor) -> Tensor:
+    """InstanceNorm2d(affine=True), biased variance, eps 1e-5, no running stats
+    (reference Resnet.py:176-178, 534-536)."""
+    return F.instance_norm(x, None, None, sd.get(key + ".weight"), sd.get(key + ".bias"),
+                           True, BN_MOMENTUM, BN_EPS)
+
+
+def conv(sd: Dict[str, Tensor], key: str, x: Tensor, stride=1, padding=0, dilation=1) -> Tensor:
+    return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride, padding, dilation)
+
+
+def upsample_bilinear_ac(x: Tensor, size: Sequence[int]) -> Tensor:
+    """reference mynn.py:114-119."""
+    return F.interpolate(x, size=tuple(int(s) for s in size), mode="bilinear", align_corners=True)
+
+
+def nearest_src_index(in_size: int, out_size: int, scale_factor: Optional[float]) -> np.ndarray:
+    """Source index of every destination index of ``F.interpolate(mode='nearest')``.
+
+    ATen computes ``src = min(floor(dst * scale), in-1)`` in fp32, with
+    ``scale = 1/scale_factor`` when a scale factor was given (recompute_scale_factor unset)
+    and ``scale = in/out`` when only an output size was given.  Restated in numpy float32 so
+    that the exact rounding at bin edges is part of the oracle (SURVEY 'Hard parts')."""
+    if scale_factor is not None:
+        scale = np.float32(1.0 / scale_factor)
+    else:
+        scale = np.float32(in_size) / np.float32(out_size)
+    dst = np.arange(out_size, dtype=np.float32)
+    src = np.floor(dst * scale).astype(np.int64)
+    return np.minimum(src, in_size - 1)
+
+
+def nearest_out_size(in_size: int, scale_factor: float) -> int:
+    """Output extent ATen picks for a scale factor: floor(in * scale) in double."""
+    return int(math.floor(float(in_size) * scale_factor))
+
+
+def np_plus(feat: Tensor, alpha: Tensor, beta_noise: Tensor) -> Tensor:
+    """Normalization-Perturbation-Plus (reference deepv3.py:268-277).
+
+    ``alpha`` ~ N(1, 0.75) and ``beta_noise`` ~ N(0, 0.75), both [B,C,1,1], are the two
+    normal draws the reference makes internally; here they are inputs."""
+    mu = feat.mean((2, 3), keepdim=True)
+    sd_b = torch.std(mu, 0, keepdim=True)               # unbiased, over the batch
+    scale = sd_b / sd_b.max() * 1.5
+    beta = 1 + beta_noise * scale
+    return alpha * feat - alpha * mu + beta * mu
+
+
+def cross_entropy_255(logits: Tensor, target: Tensor) -> Tensor:
+    """nn.CrossEntropyLoss(ignore_index=255), mean over valid pixels (reference main.py:822)."""
+    return F.cross_entropy(logits, target, ignore_index=255)
+
+
+# --------------------------------------------------------------------------------------
+# model
+# --------------------------------------------------------------------------------------
+def _bottleneck(sd, pre, x, stride, dilation, has_down, iw_affine, train, new_stats):
+    """reference Resnet.py:192-227 (one Bottleneck, list-in/list-out dropped)."""
+    out = conv(sd, pre + "conv1", x)
+    out = F.relu(batch_norm(sd, pre + "bn1", out, train, new_stats))
+    out = conv(sd, pre + "conv2", out, stride=stride, padding=dilation, dilation=dilation)
+    out = F.relu(batch_norm(sd, pre + "bn2", out, train, new_stats))
+    out = conv(sd, pre + "conv3", out)
+    out = batch_norm(sd, pre + "bn3", out, train, new_stats)
+    res = x
+    if has_down:
+        res = conv(sd, pre + "downsample.0", x, stride=stride)
+        res = batch_norm(sd, pre + "downsample.1", res, train, new_stats)
+    out = out + res
+    if iw_affine:
+        out = instance_norm(sd, pre + "instance_norm_layer", out)
+    return F.relu(out)
+
+
+def _stage(sd, name, planes, blocks, stride, dilation, x, iw, train, new_stats):
+    """reference Resnet.py:570-585: the iw module sits on the LAST block only."""
+    for i in range(blocks):
+        first = i == 0
+        x = _bottleneck(sd, f"{name}.{i}.", x,
+                        stride=stride if first else 1,
+                        dilation=dilation,
+                        has_down=first,
+                        iw_affine=(iw == 4 and i == blocks - 1 and blocks > 1),
+                        train=train, new_stats=new_stats)
+    return x
+
+
+def hrfp_branch(sd, xp: Tensor, h: int, w: int, train: bool, new_stats=None,
+                taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+    """HRFP over-complete random auto-encoder (reference deepv3.py:320-327).
+    Returns (OCout_dec [B,256,h/2,w/2], OCout [B,64,ceil(h/4),ceil(w/4)])."""
+    t = xp
+    dec_tap = None
+    for i, (ck, bk, dil, kind, arg) in enumerate(HRFP_STAGES):
+        t = conv(sd, ck, t, stride=1, padding=dil, dilation=dil)
+        if kind == "scale":
+            t = F.interpolate(t, scale_factor=(arg, arg))
+        elif kind == "half":
+            t = F.interpolate(t, size=(int(h / 2), int(w / 2)))
+        else:
+            t = F.interpolate(t, size=(math.ceil(h / 4), math.ceil(w / 4)))
+        t = F.relu(batch_norm(sd, bk, t, train, new_stats))
+        if taps is not None:
+            taps[f"hrfp{i}"] = t
+        if i == 3:
+            dec_tap = t
+    return dec_tap, t
+
+
+def aspp(sd, x: Tensor, train: bool, new_stats=None) -> Tensor:
+    """reference deepv3.py:114-126; output channel order: img-pool, 1x1, d6, d12, d18."""
+    size = x.shape[2:]
+    img = F.adaptive_avg_pool2d(x, 1)
+    img = F.relu(batch_norm(sd, "aspp.img_conv.1", conv(sd, "aspp.img_conv.0", img), train, new_stats))
+    outs = [upsample_bilinear_ac(img, size)]
+    for i, r in enumerate((0, 6, 12, 18)):
+        y = conv(sd, f"aspp.features.{i}.0", x, padding=r, dilation=max(r, 1))
+        outs.append(F.relu(batch_norm(sd, f"aspp.features.{i}.1", y, train, new_stats)))
+    return torch.cat(outs, 1)
+
+
+def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None, *,
+                 training: bool = True, bn_train: Optional[bool] = None,
+                 toggles: Tuple[bool, bool, bool] = (True, True, True),
+                 noise: Optional[Dict[str, Tensor]] = None,
+                 new_stats: Optional[Dict[str, Tensor]] = None,
+                 taps: Optional[dict] = None,
+                 perturb: bool = True):
+    """Functional MRFPPlus.forward (reference deepv3.py:280-367).
+
+    toggles = (o1, npp, o2) = (p<0.5, p2<0.5, p3<0.5) of the reference; all three are
+    only honoured when ``training`` (the reference keys them on the *argument*, while the
+    norm layers follow module mode = ``bn_train``, default = ``training``).
+    noise = {'np1_alpha','np1_beta','np2_alpha','np2_beta'} normal draws for NP+.
+    ``perturb=False`` gives simpleDeepV3Plus.forward (reference deepv3.py:451-490).
+    Returns the scalar loss when ``training`` else the logits."""
+    if bn_train is None:
+        bn_train = training
+    o1, npp, o2 = (bool(t) and training and perturb for t in toggles)
+    h, w = int(x.shape[2]), int(x.shape[3])
+    taps = taps if taps is not None else {}
+
+    # stem: conv7x7 s2 -> InstanceNorm(affine) -> ReLU -> maxpool3x3 s2 (deepv3.py:309-315)
+    t = conv(sd, "layer0.0", x, stride=2, padding=3)
+    if "layer0.1.running_mean" in sd:           # plain trunk (wt_layer[2]==0): BatchNorm stem
+        t = batch_norm(sd, "layer0.1", t, bn_train, new_stats)
+    else:
+        t = instance_norm(sd, "layer0.1", t)
+    t = F.max_pool2d(F.relu(t), 3, 2, 1)
+    xp = t
+    taps["stem"] = xp
+    if npp:
+        t = np_plus(xp, noise["np1_alpha"], noise["np1_beta"])
+        taps["np1"] = t
+    if perturb:
+        oc_dec, oc = hrfp_branch(sd, xp, h, w, bn_train, new_stats, taps)
+        if o1:
+            t = oc + t
+    iw_l1 = 4 if "layer1.2.instance_norm_layer.weight" in sd else 0
+    iw_l2 = 4 if "layer2.3.instance_norm_layer.weight" in sd else 0
+    t = _stage(sd, "layer1", 64, 3, 1, 1, t, iw_l1, bn_train, new_stats)
+    if npp:
+        t = np_plus(t, noise["np2_alpha"], noise["np2_beta"])
+    low = t
+    taps["layer1"] = low
+    t = _stage(sd, "layer2", 128, 4, 2, 1, t, iw_l2, bn_train, new_stats)
+    taps["layer2"] = t
+    t = _stage(sd, "layer3", 256, 6, 2, 1, t, 0, bn_train, new_stats)
+    taps["layer3"] = t
+    # D16: layer4 conv2 dilation 2 / stride 1, downsample stride 1 (deepv3.py:184-189)
+    t = _stage(sd, "layer4", 512, 3, 1, 2, t, 0, bn_train, new_stats)
+    taps["layer4"] = t
+
+    t = aspp(sd, t, bn_train, new_stats)
+    taps["aspp"] = t
+    up = F.relu(batch_norm(sd, "bot_aspp.1", conv(sd, "bot_aspp.0", t), bn_train, new_stats))
+    fine = F.relu(batch_norm(sd, "bot_fine.1", conv(sd, "bot_fine.0", low), bn_train, new_stats))
+    up = upsample_bilinear_ac(up, low.shape[2:])
+    d = torch.cat([fine, up], 1)
+    d = F.relu(batch_norm(sd, "final1.1", conv(sd, "final1.0", d, padding=1), bn_train, new_stats))
+    d = F.relu(batch_norm(sd, "final1.4", conv(sd, "final1.3", d, padding=1), bn_train, new_stats))
+    taps["dec1"] = d
+    if o2:
+        d = upsample_bilinear_ac(d, (int(h / 2), int(w / 2)))
+        d = oc_dec + d
+    logits = upsample_bilinear_ac(conv(sd, "final2.0", d), (h, w))
+    taps["logits"] = logits
+    if training:
+        return cross_entropy_255(logits, gts)
+    return logits
+
+
+# --------------------------------------------------------------------------------------
+# train-step / eval harness (reference main.py:822-839, 857-864, 887-913)
+# --------------------------------------------------------------------------------------
+def poly_lr_factor(it: int, max_iter: int = 40000, power: float = 0.9) -> float:
+    """reference main.py:832-839."""
+    return math.pow(1 - it / max_iter, power)
+
+
+def sgd_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], mom: Dict[str, Tensor], *,
+             lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, first: bool) -> None:
+    """torch.optim.SGD update rule (reference main.py:826): g += wd*p ; buf = g (first step)
+    or momentum*buf + g ; p -= lr*buf.  In place on ``params``/``mom``."""
+    for k, p in params.items():
+        g = grads.get(k)
+        if g is None:
+            continue
+        g = g.add(p, alpha=weight_decay)
+        if first or k not in mom:
+            mom[k] = g.clone()
+        else:
+            mom[k].mul_(momentum).add_(g)
+        p.add_(mom[k], alpha=-lr)
+
+
+def trainable_keys(sd: Dict[str, Tensor]):
+    """Parameters the reference optimises: everything that is a Parameter and not part of the
+    frozen HRFP branch (deepv3.py:221-237 ``requires_grad_(False)``)."""
+    out = []
+    for k in sd:
+        if k.startswith("OC"):
+            continue
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            continue
+        out.append(k)
+    return out
+
+
+def train_steps(sd: Dict[str, Tensor], batches, toggles_seq, noise_seq, *, lr=1e-2, n_iter_max=40000):
+    """Runs len(batches) train iterations (zero_grad -> backward -> step -> sched.step);
+    returns the list of losses.  ``sd`` is updated in place (weights and BN running stats)."""
+    keys = trainable_keys(sd)
+    mom: Dict[str, Tensor] = {}
+    losses = []
+    for it, ((x, y), tg, nz) in enumerate(zip(batches, toggles_seq, noise_seq)):
+        leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+        work = dict(sd)
+        work.update(leaf)
+        new_stats: Dict[str, Tensor] = {}
+        loss = mrfp_forward(work, x, y, training=True, toggles=tg, noise=nz, new_stats=new_stats)
+        grads = torch.autograd.grad(loss, [leaf[k] for k in keys], allow_unused=True)
+        gd = {k: g for k, g in zip(keys, grads) if g is not None}
+        with torch.no_grad():
+            params = {k: sd[k] for k in keys}
+            sgd_step(params, gd, mom, lr=lr * poly_lr_factor(it, n_iter_max), first=(it == 0))
+            for k, v in new_stats.items():
+                sd[k].copy_(v)
+        losses.append(float(loss.detach()))
+    return losses
+
+
+def fast_hist(label_pred: np.ndarray, label_true: np.ndarray, num_classes: int = 19) -> np.ndarray:
+    """reference metrics.py:122-126: rows = ground truth, columns = prediction."""
+    mask = (label_true >= 0) & (label_true < num_classes)
+    idx = num_classes * label_true[mask].astype(np.int64) + label_pred[mask].astype(np.int64)
+    return np.bincount(idx, minlength=num_classes ** 2).reshape(num_classes, num_classes)
+
+
+def miou_from_hist(hist: np.ndarray) -> Tuple[float, np.ndarray]:
+    """reference metrics.py:60-85: IoU_c = diag / (rowsum + colsum - diag); mIoU = nanmean."""
+    hist = hist.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+    return float(np.nanmean(iu)), iu
+
+
+def eval_hist(sd, x: Tensor, y: Tensor) -> np.ndarray:
+    """One eval iteration of reference main.py:896-908 (model.eval(), training=False)."""
+    with torch.no_grad():
+        logits = mrfp_forward(sd, x, training=False, bn_train=False)
+    pred = logits.numpy().argmax(1)
+    return fast_hist(pred.flatten(), y.numpy().astype("int64").flatten(), logits.shape[1])
