@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the MRFP+ training hot path (one step = forward + backward + fused SGD on one synthetic
+batch, inputs resident in HBM).  Contract: prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json's metric is quoted on ResNet-101 DeepLabV3+ + MRFP+ at 768x768,
+16 images per GPU, bf16 activations (configs[2]; configs[3] = the same per rank on 8 GPUs, weak scaling).
+All three perturbation toggles are forced ON (worst case).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X (guide: ~2.5 PF dense)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--trunk", default="resnet-101", choices=["resnet-50", "resnet-101"])
+    ap.add_argument("--size", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--backend", default="hip", choices=["hip", "miopen"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+class HipTimer:
+    """hipEvents on a given stream through libamdhip64 (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so.7")   # the copy torch already loaded (same SONAME)
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+
+    def event(self):
+        e = ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+        return e
+
+    def record(self, e, stream):
+        assert self.hip.hipEventRecord(e, ctypes.c_void_p(stream)) == 0
+
+    def elapsed_ms(self, a, b):
+        self.hip.hipEventSynchronize(b)
+        ms = ctypes.c_float()
+        assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+        return ms.value
+
+
+def cpu_baseline(args, seconds):
+    """The CPU oracle (a port of the reference arithmetic, validated bit-exact against the reference in the
+    build container) timed on this host's cores on a bounded sample of the same workload."""
+    import json as js
+    from mrfp_amd import synth
+    from oracle import mrfp_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    from mrfp_amd import deepv3
+    from mrfp_amd.config import cfg
+    m = deepv3.MRFPPlus(19, trunk=args.trunk)
+    spec = synth.spec_of(m.state_dict())
+    del m
+    sd = synth.synth_state_dict(spec, seed=0)
+    B, S = 2, 256
+    x, y = synth.synth_batch(B, S, S, seed=1)
+    noise = synth.synth_noise(B, seed=2)
+    if args.trunk == "resnet-101":
+        noise["np1_alpha"] = noise["np1_alpha"].repeat(1, 2, 1, 1)
+        noise["np1_beta"] = noise["np1_beta"].repeat(1, 2, 1, 1)
+    keys = orc.trainable_keys(sd)
+
+    def step():
+        leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+        work = dict(sd)
+        work.update(leaf)
+        loss = orc.mrfp_forward(work, x, y, training=True, toggles=(True, True, True), noise=noise)
+        torch.autograd.grad(loss, [leaf[k] for k in keys])
+    step()
+    t0, n = time.time(), 0
+    while n < 3 or time.time() - t0 < seconds:
+        step()
+        n += 1
+        if time.time() - t0 > 3 * seconds:
+            break
+    dt_ = time.time() - t0
+    return {"value": round(B * n / dt_, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d train steps (fwd+bwd) of %s MRFP+ at %dx%dx%d fp32 on the CPU oracle; "
+                      "work/image scales with H*W (x%.0f at %dx%d)" % (n, args.trunk, B, S, S,
+                                                                      (args.size / S) ** 2, args.size, args.size)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from mrfp_amd import synth, deepv3
+    from mrfp_amd.config import cfg
+    from mrfp_amd.harness import Trainer
+    cfg.MODEL.CONV_BACKEND = args.backend
+    cfg.MODEL.ACT_DTYPE = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = deepv3.MRFPPlus(19, trunk=args.trunk, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
+    model.load_state_dict(synth.synth_state_dict(synth.spec_of(model.state_dict()), seed=0))
+    model = model.to(dev).train()
+    model.rng = deepv3.InjectedRandom((True, True, True), None, reinit=True)   # all perturbations on, HRFP re-drawn
+    trainer = Trainer(model)
+    x, y = synth.synth_batch(args.batch, args.size, args.size, seed=1 + rank)
+    x, y = x.to(dev), y.to(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    lossv = float(loss)
+
+    out = None
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = args.batch * world * args.steps / elapsed
+        # roofline of the dominant kernel family (the MFMA implicit-GEMM convolutions): algorithmic FLOPs of
+        # all conv launches of one step / their summed device time, measured with hipEvents around each launch
+        roof = None
+        if args.backend == "hip":
+            roof = conv_roofline(model, trainer, x, y, args)
+        out = {"metric": "train images/sec", "value": round(value, 3), "unit": "images/sec", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "%s DeepLabV3+ + MRFP+ (HRFP+NP+ on, HRFP re-drawn every step), %dx%d, "
+                                      "%d images/GPU, fwd+bwd+SGD, synthetic 19-class, random-init weights"
+                                      % (args.trunk, args.size, args.size, args.batch),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "conv_backend": args.backend, "final_loss": round(lossv, 5)},
+               "roofline": roof}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+
+
+def conv_roofline(model, trainer, x, y, args):
+    """Times every MFMA convolution launch (fwd / dgrad / wgrad) of one train step with hipEvents recorded on
+    the launch stream, and divides their algorithmic FLOPs by the summed durations."""
+    import mrfp_amd.conv as conv_mod
+    from mrfp_amd import _lib
+    timer = HipTimer()
+    events, flops = [], []
+    orig = _lib.call
+    st = torch.cuda.current_stream().cuda_stream
+
+    def spy(name, *a):
+        if name in ("mrfp_conv_fwd", "mrfp_conv_wgrad"):
+            if name == "mrfp_conv_fwd":
+                B, H, W, C, N, ldy, R, S, Ho, Wo = a[5:15]
+                f = 2.0 * B * Ho * Wo * N * R * S * C / float(a[19] * a[19])
+            else:
+                B, H, W, C, Ct, N, ldn, R, S, Ho, Wo = a[5:16]
+                f = 2.0 * B * Ho * Wo * N * R * S * C
+            e0, e1 = timer.event(), timer.event()
+            timer.record(e0, st)
+            r = orig(name, *a)
+            timer.record(e1, st)
+            events.append((e0, e1))
+            flops.append(f)
+            return r
+        return orig(name, *a)
+    conv_mod.call = spy
+    try:
+        trainer.step(x, y)
+        torch.cuda.synchronize()
+    finally:
+        conv_mod.call = orig
+    ms = [timer.elapsed_ms(a, b) for a, b in events]
+    tot_ms, tot_f = sum(ms), sum(flops)
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    ach = tot_f / (tot_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(ms),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": None, "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,212 @@
+/*
+ * mrfp_hip.h -- C ABI of libmrfp_hip.so: the MI355X (gfx950) kernels behind the MRFP+ training
+ * hot path (reference airl-iisc/MRFP: deepv3.py:152-367 and its callees).
+ *
+ * The reference has no native code and no FFI: its hot path is torch.nn modules calling
+ * ATen/cuDNN.  Each entry point below names the reference call site (file:line) whose
+ * arithmetic it replaces.  The Python side (mrfp_amd/ops.py) binds these with ctypes; see
+ * INTEGRATION.md for the binding stub and the nn.Module drop-in surface.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE pointers.
+ *  - activations are NHWC ("channels-last"): x[b][h][w][c], dense, dtype MRFP_F32 or MRFP_BF16.
+ *    Statistics, coefficients, losses and weights' master copies are always fp32.
+ *  - the caller allocates every output and every workspace; nothing is allocated, freed or
+ *    synchronised inside; every launch goes to `stream` (a hipStream_t passed as void*).
+ *  - return 0 on success, negative on error; the message is mrfp_last_error() (thread-local).
+ *  - "geometry" arguments shared by the row kernels:
+ *      B, Ho, Wo, C  : logical (destination) tensor [B,Ho,Wo,C]
+ *      Hs, Ws        : source tensor [B,Hs,Ws,C] when the op reads through a nearest-neighbour
+ *                      resize (HRFP, reference deepv3.py:320-327); Hs==Ho, Ws==Wo otherwise
+ *      tabH, tabW    : int32 device tables, tabH[oh] = source row of destination row oh
+ *                      (NULL = identity).  Built on the host with ATen's float32 rule.
+ */
+#ifndef MRFP_HIP_H
+#define MRFP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MRFP_F32 = 0, MRFP_BF16 = 1 } mrfp_dtype;
+
+int mrfp_version(void);
+const char* mrfp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-channel statistics over NHWC rows.  Replaces the reductions inside F.batch_norm
+ * (reference mynn.py:19-25 Norm2d), nn.InstanceNorm2d (reference Resnet.py:176-178, 534-536),
+ * feat.mean((2,3)) of NP+ (reference deepv3.py:269) and AdaptiveAvgPool2d(1) (deepv3.py:109).
+ *
+ * Workspace layout: float ws[B][nslab][2][C] with nslab = mrfp_stats_nslab(B, Ho);
+ * ws[b][s][0][c] = partial sum, ws[b][s][1][c] = partial sum of squares (fwd), or
+ * partial sum of dy' and of dy'*(x-mean) (bwd).
+ * ------------------------------------------------------------------------------------------- */
+int64_t mrfp_stats_nslab(int64_t B, int64_t Ho);
+
+int mrfp_stats_fwd(const void* x, int dtype, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
+                   int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW,
+                   float* ws, void* stream);
+
+/* dy' = dy * (y > 0) when y != NULL (ReLU mask taken from the forward output), else dy.
+ * mean: float [G][C] (G = B if per_image else 1) or NULL (=0). */
+int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* mean, int per_image,
+                   int dtype, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
+                   int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW,
+                   float* ws, void* stream);
+
+/* BatchNorm (train): statistics over B*Ho*Wo; biased var for normalisation, unbiased for the
+ * running update (momentum).  Outputs mean[C], invstd[C] and the apply coefficients
+ * A[c] = w*invstd, S[c] = b - mean*A.  running_* may be NULL. */
+int mrfp_bn_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C,
+                     const float* weight, const float* bias, float eps, float momentum,
+                     float* running_mean, float* running_var,
+                     float* mean, float* invstd, float* A, float* S, void* stream);
+/* BatchNorm (eval): coefficients from the running statistics. */
+int mrfp_bn_eval_coef(int64_t C, const float* weight, const float* bias, const float* running_mean,
+                      const float* running_var, float eps, float* A, float* S, void* stream);
+/* backward: dweight[C], dbias[C] and the input-gradient coefficients
+ * dx = P*dy' + Q*x + R  (per channel). */
+int mrfp_bn_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C,
+                         const float* weight, const float* mean, const float* invstd,
+                         float* dweight, float* dbias, float* P, float* Q, float* R, void* stream);
+
+/* InstanceNorm2d(affine): statistics per (b,c) over Ho*Wo, biased variance.  weight/bias may be
+ * NULL (affine=False, reference instance_whitening.py:5-16).  Outputs are [B][C]. */
+int mrfp_in_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C,
+                     const float* weight, const float* bias, float eps,
+                     float* mean, float* invstd, float* A, float* S, void* stream);
+/* dweight/dbias are accumulated over b inside (written, not added). */
+int mrfp_in_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C,
+                         const float* weight, const float* mean, const float* invstd,
+                         float* dweight, float* dbias, float* P, float* Q, float* R, void* stream);
+
+/* NP+ (reference deepv3.py:268-277).  alpha, beta_noise: the two normal draws, float [B][C].
+ * fwd: mu[B][C] = plane means; sigma[C] = unbiased std over the batch; scale = 1.5*sigma/max(sigma);
+ *      y = A*x + S with A = alpha, S = (1 + beta_noise*scale - alpha)*mu.
+ * bwd: from G[b][c] = sum_hw dy (ws from mrfp_stats_bwd with y=NULL, mean=NULL) produces the
+ *      per-plane additive constant K so that dx = alpha*dy + K  (gradients flow through mu,
+ *      sigma and the max exactly as autograd does for the reference expression). */
+int mrfp_np_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C,
+                     const float* alpha, const float* beta_noise,
+                     float* mu, float* sigma, float* A, float* S, void* stream);
+int mrfp_np_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C,
+                         const float* alpha, const float* beta_noise, const float* mu,
+                         const float* sigma, float* Gtmp /* scratch [B][C] */, float* K, void* stream);
+
+/* Plane means only (AdaptiveAvgPool2d(1), reference deepv3.py:109,117): out[B][C] (dtype);
+ * tmp: fp32 scratch [B][C].  Its backward (broadcast of g/(H*W)) is mrfp_affine_fwd with x = NULL. */
+int mrfp_mean_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C,
+                       float* tmp, void* out, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Apply kernels.
+ * fwd:  y[b,oh,ow,c] = act( x[b,tabH[oh],tabW[ow],c] * A[g,c] + S[g,c] + res[b,oh,ow,c] )
+ *       g = b if coef_per_image else 0;  res may be NULL;  relu = 0/1.
+ *       A == NULL means A = 1 (pure broadcast add of S), x == NULL means x = 0.
+ * bwd:  dy' = dy * (y > 0) if y != NULL
+ *       dx[b,ih,iw,c] = sum over destinations mapped to (ih,iw) of P*dy'  + n*(Q*x + R)
+ *       (n = number of such destinations; invH/invW give their half-open ranges:
+ *        destination rows [invH[2*ih], invH[2*ih+1]) map to source row ih; NULL = identity)
+ *       dres (optional, same geometry as dy) receives dy'.
+ * ------------------------------------------------------------------------------------------- */
+int mrfp_affine_fwd(const void* x, const void* res, void* y, int dtype,
+                    int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
+                    const int32_t* tabH, const int32_t* tabW,
+                    const float* A, const float* S, int coef_per_image, int relu, void* stream);
+
+int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int dtype,
+                    int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
+                    const int32_t* invH, const int32_t* invW,
+                    const float* P, const float* Q, const float* R, int coef_per_image,
+                    void* stream);
+
+/* y = a + b, elementwise over n elements (torch.add of reference deepv3.py:330, 357). */
+int mrfp_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=True (reference mynn.py:114-119 Upsample).
+ * fwd: y[B,Ho,Wo,C] = bilinear(x[B,Hi,Wi,0:C]) (+ addend[B,Ho,Wo,C] if not NULL; deepv3.py:356-357)
+ * bwd: dx[B,Hi,Wi,0:C] = adjoint applied to dy[B,Ho,Wo,C]  (gather form, no atomics)
+ * ld_in: channel pitch of the low-resolution tensor (>= C; the 19-class logits are kept in a
+ *        32-channel padded buffer at low resolution so that the final 1x1 conv stays chunk-aligned).
+ * ------------------------------------------------------------------------------------------- */
+int mrfp_bilinear_fwd(const void* x, const void* addend, void* y, int dtype,
+                      int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo, int64_t C, int64_t ld_in,
+                      void* stream);
+int mrfp_bilinear_bwd(const void* dy, void* dx, int dtype,
+                      int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo, int64_t C, int64_t ld_in,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MaxPool2d(kernel 3, stride 2, padding 1) (reference Resnet.py:551, deepv3.py:315).
+ * y[B,Ho,Wo,C], Ho = (H-1)/2+1; idx[B,Ho,Wo,C] (uint8) stores the window position 0..8 of the
+ * first maximum.  bwd (gather form): dx[B,H,W,C] = sum of dy over windows whose arg-max is this pixel.
+ * ------------------------------------------------------------------------------------------- */
+int mrfp_maxpool_fwd(const void* x, void* y, uint8_t* idx, int dtype,
+                     int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int mrfp_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype,
+                     int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CrossEntropyLoss(ignore_index=255), mean over valid pixels (reference main.py:822,
+ * deepv3.py:363).  logits [B,H,W,C] NHWC (dtype), target int64 [B,H,W].
+ * ws: float [2*nblk] with nblk = mrfp_ce_nblocks(B*H*W).
+ * fwd writes loss[0] = mean NLL, loss[1] = number of valid pixels (fp32).
+ * bwd: dlogits = (softmax - onehot) * gscale[0] / nvalid  for valid pixels, 0 otherwise.
+ * ------------------------------------------------------------------------------------------- */
+int64_t mrfp_ce_nblocks(int64_t npix);
+int mrfp_ce_fwd(const void* logits, const int64_t* target, int dtype, int64_t npix, int64_t C,
+                int64_t ignore_index, float* ws, float* loss, void* stream);
+int mrfp_ce_bwd(const void* logits, const int64_t* target, const float* loss, const float* gscale,
+                void* dlogits, int dtype, int64_t npix, int64_t C, int64_t ignore_index, void* stream);
+
+/* Eval: argmax over classes + 19x19 confusion histogram on the device (reference main.py:898-909,
+ * metrics.py:122-126): hist[num_classes*gt + pred] += 1 for gt in [0,num_classes).  hist: int64
+ * [C*C], accumulated (not cleared).  pred (optional, uint8 [npix]) receives the arg-max. */
+int mrfp_argmax_hist(const void* logits, const int64_t* target, int dtype, int64_t npix, int64_t C,
+                     int64_t* hist, uint8_t* pred, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution on the matrix cores (implicit GEMM, NHWC).  Replaces every nn.Conv2d of the hot
+ * path (reference Resnet.py:156-161, deepv3.py:96-112, 200-237) and its autograd backward.
+ *
+ * mrfp_pack_weight: OIHW fp32 master [N][C][R][S] -> forward pack wf[Npad][R][S][Cpad] and
+ *   dgrad pack wd[C][R][S][Npad] (taps flipped), both in `dtype`, pad entries zero.
+ * mrfp_conv_fwd:  y[B,Ho,Wo,0:N] (pitch ldy) = conv(x[B,H,W,C], wpack) + bias
+ *   output position o reads source position o*stride - pad + r*dil; with sstride > 1 the tap
+ *   exists only where that position is a multiple of sstride (then index = position / sstride):
+ *   this is the dgrad of a strided convolution, run on dy with the wd pack.
+ *   C*sizeof(dtype) must be a multiple of 16 (pad the channels).
+ * mrfp_conv_wgrad: dw[N][Ctrue][R][S] (fp32, OIHW) = sum over pixels of dy[.,n] * x[tap(.),c];
+ *   ws: mrfp_conv_wgrad_ws_bytes(M = B*Ho*Wo, N, Q = R*S*C) bytes of scratch (split-K slabs,
+ *   summed in a fixed order: bitwise reproducible).
+ * mrfp_nchw_to_nhwc_pad: network input NCHW fp32 -> NHWC `dtype` with zero pad channels.
+ * ------------------------------------------------------------------------------------------- */
+int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, int64_t C, int64_t R, int64_t S,
+                     int64_t Npad, int64_t Cpad, void* stream);
+int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype,
+                  int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,
+                  int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil,
+                  int64_t sstride, void* stream);
+int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q);
+int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype,
+                    int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,
+                    int64_t R, int64_t S, int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w,
+                    int64_t dil, void* stream);
+int mrfp_nchw_to_nhwc_pad(const float* x, void* y, int dtype, int64_t B, int64_t C, int64_t H, int64_t W,
+                          int64_t Cpad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused SGD(momentum, weight decay) over a flat fp32 arena (reference main.py:826-839, 863-864):
+ *   g' = g*gscale + wd*p ; m = g' (first) | momentum*m + g' ; p -= lr*m.   n % 4 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int mrfp_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum,
+                  float weight_decay, float gscale, int first, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRFP_HIP_H */

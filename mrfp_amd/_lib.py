@@ -1,0 +1,93 @@
+"""ctypes binding of libmrfp_hip.so (C ABI declared in include/mrfp_hip.h).
+
+The prototypes are parsed from the header itself, so the header is the single source of truth
+for the boundary.  There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so both sides share one HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "mrfp_hip.h")
+LIBPATH = os.path.join(_HERE, "csrc", "libmrfp_hip.so")
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+class MrfpHipError(RuntimeError):
+    pass
+
+
+def parse_header(path: str = HEADER):
+    """-> {name: (restype, [argtypes])} for every `mrfp_*` prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(mrfp_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}.get(ret.strip(), ctypes.c_char_p)
+        argtypes = []
+        for a in args.split(","):
+            a = a.strip()
+            if a in ("", "void"):
+                continue
+            if "*" in a:
+                argtypes.append(ctypes.c_void_p)
+            elif a.startswith("int64_t"):
+                argtypes.append(ctypes.c_int64)
+            elif a.startswith("float"):
+                argtypes.append(ctypes.c_float)
+            elif a.startswith("int"):
+                argtypes.append(ctypes.c_int)
+            else:
+                raise MrfpHipError("cannot parse argument %r of %s" % (a, name))
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise MrfpHipError(
+                "libmrfp_hip.so is not built (%s). Run `python -m mrfp_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no fallback path." % LIBPATH)
+        cdll = ctypes.CDLL(LIBPATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(cdll, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = cdll
+    return _lib
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise MrfpHipError("unsupported activation dtype %s (float32 / bfloat16 only)" % t.dtype)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Calls an int-returning entry point and raises with mrfp_last_error() on failure."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise MrfpHipError("%s failed (%d): %s" % (name, rc, lib().mrfp_last_error().decode()))

@@ -1,0 +1,62 @@
+"""Global configuration knob set, mirroring the reference's `cfg` AttrDict (reference config.py:46-93,
+utils/attr_dict.py).  The only knob the reference's hot path reads is cfg.MODEL.BNFUNC
+(config.py:92-93, used by mynn.Norm2d); the build adds the activation dtype and the conv backend.
+"""
+import torch
+
+
+class AttrDict(dict):
+    """dict with attribute access and an immutability switch (reference utils/attr_dict.py)."""
+
+    IMMUTABLE = "__immutable__"
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.__dict__[AttrDict.IMMUTABLE] = False
+
+    def __getattr__(self, name):
+        if name in self.__dict__:
+            return self.__dict__[name]
+        if name in self:
+            return self[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if self.__dict__[AttrDict.IMMUTABLE]:
+            raise AttributeError('Attempted to set "%s" to "%s", but AttrDict is immutable' % (name, value))
+        if name in self.__dict__:
+            self.__dict__[name] = value
+        else:
+            self[name] = value
+
+    def immutable(self, is_immutable):
+        self.__dict__[AttrDict.IMMUTABLE] = is_immutable
+        for v in list(self.__dict__.values()) + list(self.values()):
+            if isinstance(v, AttrDict):
+                v.immutable(is_immutable)
+
+    def is_immutable(self):
+        return self.__dict__[AttrDict.IMMUTABLE]
+
+
+cfg = AttrDict()
+cfg.ITER = 0
+cfg.EPOCH = 0
+cfg.MODEL = AttrDict()
+cfg.MODEL.BN = "hip-batchnorm"
+# set lazily by network.mynn (the HIP BatchNorm2d subclass); the reference default is
+# torch.nn.SyncBatchNorm, which on one process is plain batch statistics.
+cfg.MODEL.BNFUNC = None
+# activation storage dtype of the HIP path: torch.float32 (parity runs) or torch.bfloat16 (bench)
+cfg.MODEL.ACT_DTYPE = torch.float32
+# 'hip' = hand-written MFMA implicit-GEMM kernels; 'miopen' = stock ROCm convolution through ATen
+cfg.MODEL.CONV_BACKEND = "hip"
+# directory searched for ImageNet checkpoints when pretrained=True (no network access here)
+cfg.MODEL.PRETRAINED_DIR = None
+
+
+def assert_and_infer_cfg(args=None, make_immutable=True, train_mode=True):
+    """reference config.py:95-128.  Both settings of `syncbn` map to the HIP BatchNorm: per-replica
+    statistics are the reference's single-GPU semantics."""
+    if make_immutable:
+        cfg.immutable(True)

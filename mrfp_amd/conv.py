@@ -1,0 +1,154 @@
+"""nn.Conv2d forward / backward on the MFMA implicit-GEMM kernels (mrfp_amd/csrc/conv.hip).
+
+The OIHW fp32 Parameter stays the master copy (checkpoint ABI, optimiser state); the kernels read
+two derived packs in the activation dtype -- forward [N][R][S][C] and dgrad [C][R][S][N] with flipped
+taps -- rebuilt by one small kernel whenever the Parameter's version counter moves (optimizer
+step, HRFP re-initialisation, load_state_dict).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import call, dt, ptr, stream
+from .ops import CL, _chk, empty_cl, zeros_cl
+
+_PACKS = {}      # id(weight Parameter) -> {key: _Pack}; entry dropped when the Parameter dies
+_EPOCH = [0]     # bumped by writers that bypass autograd's version counters (the fused SGD kernel)
+
+
+def invalidate_packs():
+    _EPOCH[0] += 1
+
+
+def _epc(dtype) -> int:
+    """elements per 16-byte chunk"""
+    return 4 if dtype == torch.float32 else 8
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class _Pack:
+    __slots__ = ("version", "wf", "wd", "bias", "key")
+
+
+def get_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, Cphys: int, Nphys: int) -> _Pack:
+    N, C, R, S = weight.shape
+    key = (dtype, Cphys, Nphys, weight.data_ptr(), bias.data_ptr() if bias is not None else 0)
+    ver = (weight._version, bias._version if bias is not None else 0, _EPOCH[0])
+    per_w = _PACKS.get(id(weight))
+    if per_w is None:
+        per_w = {}
+        _PACKS[id(weight)] = per_w
+        weakref.finalize(weight, _PACKS.pop, id(weight), None)
+    pk = per_w.get(key)
+    if pk is not None and pk.version == ver:
+        return pk
+    dev = weight.device
+    w32 = weight.detach()
+    if w32.dtype != torch.float32 or not w32.is_contiguous():
+        w32 = w32.float().contiguous()
+    if pk is None:
+        pk = _Pack()
+        pk.wf = torch.empty(Nphys * R * S * Cphys, dtype=dtype, device=dev)
+        pk.wd = torch.empty(C * R * S * Nphys, dtype=dtype, device=dev)
+        pk.bias = None
+    call("mrfp_pack_weight", ptr(w32), ptr(pk.wf), ptr(pk.wd), _lib._DT[dtype], N, C, R, S, Nphys, Cphys, stream())
+    if bias is not None:
+        b32 = torch.zeros(Nphys, dtype=torch.float32, device=dev)
+        b32[:N].copy_(bias.detach())
+        pk.bias = b32
+    pk.version = ver
+    per_w[key] = pk
+    return pk
+
+
+def _out_size(H, R, stride, pad, dil):
+    return (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad_h, pad_w, dil, Nphys):
+        B, Cphys, H, W = x.shape
+        N, C, R, S = weight.shape
+        Ho, Wo = _out_size(H, R, stride, pad_h, dil), _out_size(W, S, stride, pad_w, dil)
+        pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
+        y = empty_cl(B, Nphys, Ho, Wo, x.dtype, x.device)
+        call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
+             Ho, Wo, stride, pad_h, pad_w, dil, 1, stream())
+        ctx.save_for_backward(x, weight, bias)
+        ctx.cfg = (stride, pad_h, pad_w, dil, Nphys, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        stride, pad_h, pad_w, dil, Nphys, Ho, Wo = ctx.cfg
+        dy = _chk(dy, "dy")
+        B, Cphys, H, W = x.shape
+        N, C, R, S = weight.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if Cphys != C:
+                raise _lib.MrfpHipError("dgrad through a channel-padded input is not supported")
+            pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
+            dx = empty_cl(B, Cphys, H, W, x.dtype, x.device)
+            call("mrfp_conv_fwd", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
+                 1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, stream())
+        if ctx.needs_input_grad[1]:
+            M, Q = B * Ho * Wo, R * S * Cphys
+            ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
+            dw = torch.empty((N, C, R, S), dtype=torch.float32, device=x.device)
+            call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), dt(x), B, H, W, Cphys, C, N, Nphys, R, S, Ho, Wo,
+                 stride, pad_h, pad_w, dil, stream())
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        if bias is not None and ctx.needs_input_grad[2]:
+            from .ops import _stats_fwd
+            nslab, sws = _stats_fwd(dy, None)
+            out = torch.empty(4 * Nphys, dtype=torch.float32, device=x.device)
+            call("mrfp_bn_finalize", ptr(sws), B, nslab, B * Ho * Wo, Nphys, None, None, 0.0, 0.0, None, None,
+                 ptr(out[:Nphys]), ptr(out[Nphys:2 * Nphys]), ptr(out[2 * Nphys:3 * Nphys]), ptr(out[3 * Nphys:]), stream())
+            db = (out[:N] * float(B * Ho * Wo)).to(bias.dtype)       # column mean * count = column sum
+        return dx, dw, db, None, None, None, None, None
+
+
+def pad_input_channels(x: torch.Tensor, dtype) -> torch.Tensor:
+    """Network input NCHW fp32 -> NHWC `dtype` with the channel count padded to a 16-byte chunk."""
+    if not x.is_cuda:
+        raise _lib.MrfpHipError("input must live on the GPU (got %s): the HIP path has no CPU fallback" % x.device)
+    B, C, H, W = x.shape
+    Cpad = _round_up(C, _epc(dtype))
+    xs = x.detach()
+    if xs.dtype != torch.float32 or not xs.is_contiguous():
+        xs = xs.float().contiguous()
+    y = empty_cl(B, Cpad, H, W, dtype, x.device)
+    call("mrfp_nchw_to_nhwc_pad", ptr(xs), ptr(y), _lib._DT[dtype], B, C, H, W, Cpad, stream())
+    return y
+
+
+def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] = None):
+    """x: [B,Cphys,H,W] channels-last (Cphys >= weight.shape[1], extra channels must be zero);
+    returns [B,N,Ho,Wo], or the channel-padded [B,phys_out,Ho,Wo] buffer when phys_out is given."""
+    st = stride[0] if isinstance(stride, (tuple, list)) else int(stride)
+    ph, pw = (padding if isinstance(padding, (tuple, list)) else (int(padding), int(padding)))
+    dl = dilation[0] if isinstance(dilation, (tuple, list)) else int(dilation)
+    N, C = weight.shape[0], weight.shape[1]
+    epc = _epc(x.dtype)
+    if x.shape[1] % epc != 0:                        # e.g. a raw 3-channel image: pad (copy) to a chunk
+        xp = zeros_cl(x.shape[0], _round_up(x.shape[1], epc), x.shape[2], x.shape[3], x.dtype, x.device)
+        xp[:, :x.shape[1]] = x
+        x = xp
+    if x.shape[1] < C:
+        raise _lib.MrfpHipError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], C))
+    Nphys = phys_out if phys_out is not None else _round_up(N, epc)
+    y = _Conv2d.apply(x, weight, bias, st, ph, pw, dl, Nphys)
+    if phys_out is None and Nphys != N:
+        y = y[:, :N].contiguous(memory_format=CL)
+    return y

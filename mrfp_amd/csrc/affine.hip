@@ -1,0 +1,235 @@
+// affine.hip -- the "apply" half of every normalisation / perturbation on the hot path:
+//   y = act(x[src]*A[g,c] + S[g,c] + res)           (BN / IN / NP+ apply, nearest-resize gather)
+//   dx = sum_{dst->src} P*dy' + n*(Q*x + R)          (their backward, gather form, no atomics)
+// One read of each input, one write of each output, 16 bytes per lane per instruction.
+//
+// Replaces (reference): the normalise+affine(+ReLU)(+residual add) tails of F.batch_norm /
+// InstanceNorm2d / NP+ (Resnet.py:202-225, deepv3.py:276) and F.interpolate(mode='nearest')
+// feeding BatchNorm+ReLU in the HRFP branch (deepv3.py:320-327).
+#include "common.hpp"
+
+namespace mrfp {
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                              T* __restrict__ y, RowGeom g, int ly,
+                                                              const float* __restrict__ A, const float* __restrict__ S,
+                                                              int coef_per_image, int relu) {
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(g.C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    if (trow >= L.rowthreads) return;
+    const size_t cbase = (size_t)(coef_per_image ? b : 0) * g.C;
+    for (int cv = tcol; cv < L.lpr; cv += kThreads) {
+        float a[VEC], s[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { a[i] = 1.f; s[i] = 0.f; }
+        if (A) load_coef<VEC>(A + cbase + (size_t)cv * VEC, a);
+        if (S) load_coef<VEC>(S + cbase + (size_t)cv * VEC, s);
+        for (int oh = j; oh < g.Ho; oh += ly) {
+            const int ih = g.tabH ? g.tabH[oh] : oh;
+            const T* xl = x ? x + ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC : nullptr;
+            const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
+            for (int ow = trow; ow < g.Wo; ow += L.rowthreads) {
+                const int iw = g.tabW ? g.tabW[ow] : ow;
+                float v[VEC];
+                if (xl) {
+                    load_f<T, VEC>(xl + (size_t)iw * g.C, v);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[i] = v[i] * a[i] + s[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[i] = s[i];
+                }
+                if (res) {
+                    float r[VEC];
+                    load_f<T, VEC>(res + dl + (size_t)ow * g.C, r);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[i] += r[i];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                }
+                store_f<T, VEC>(y + dl + (size_t)ow * g.C, v);
+            }
+        }
+    }
+}
+
+// Backward, walking SOURCE lines.  invH[2*ih], invH[2*ih+1] = half-open range of destination rows that
+// read source row ih (NULL = identity).  dres (destination geometry) is only supported with
+// identity maps (the residual branches of the network never sit behind a resize).
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const T* __restrict__ y, T* __restrict__ dx,
+                                                              T* __restrict__ dres, RowGeom g, int ly,
+                                                              const int32_t* __restrict__ invH,
+                                                              const int32_t* __restrict__ invW,
+                                                              const float* __restrict__ P, const float* __restrict__ Q,
+                                                              const float* __restrict__ R, int coef_per_image) {
+    // here g.Hs/g.Ws is the geometry of dx (the walked tensor), g.Ho/g.Wo that of dy
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(g.C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    if (trow >= L.rowthreads) return;
+    const size_t cbase = (size_t)(coef_per_image ? b : 0) * g.C;
+    for (int cv = tcol; cv < L.lpr; cv += kThreads) {
+        float p[VEC], q[VEC], r[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { p[i] = 1.f; q[i] = 0.f; r[i] = 0.f; }
+        if (P) load_coef<VEC>(P + cbase + (size_t)cv * VEC, p);
+        if (Q) load_coef<VEC>(Q + cbase + (size_t)cv * VEC, q);
+        if (R) load_coef<VEC>(R + cbase + (size_t)cv * VEC, r);
+        for (int ih = j; ih < g.Hs; ih += ly) {
+            const int oh0 = invH ? invH[2 * ih] : ih, oh1 = invH ? invH[2 * ih + 1] : ih + 1;
+            const size_t sl = ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
+            for (int iw = trow; iw < g.Ws; iw += L.rowthreads) {
+                const int ow0 = invW ? invW[2 * iw] : iw, ow1 = invW ? invW[2 * iw + 1] : iw + 1;
+                float acc[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                for (int oh = oh0; oh < oh1; ++oh) {
+                    const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
+                    for (int ow = ow0; ow < ow1; ++ow) {
+                        float dv[VEC];
+                        load_f<T, VEC>(dy + dl + (size_t)ow * g.C, dv);
+                        if (y) {
+                            float yv[VEC];
+                            load_f<T, VEC>(y + dl + (size_t)ow * g.C, yv);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) dv[i] = yv[i] > 0.f ? dv[i] : 0.f;
+                        }
+                        if (dres) store_f<T, VEC>(dres + dl + (size_t)ow * g.C, dv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] += dv[i];
+                    }
+                }
+                const float n = (float)((oh1 - oh0) * (ow1 - ow0));
+                float o[VEC];
+                if (x && Q) {
+                    float xv[VEC];
+                    load_f<T, VEC>(x + sl + (size_t)iw * g.C, xv);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * (q[i] * xv[i] + r[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * r[i];
+                }
+                store_f<T, VEC>(dx + sl + (size_t)iw * g.C, o);
+            }
+        }
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void add_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                       T* __restrict__ y, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads) {
+        float u[VEC], v[VEC];
+        load_f<T, VEC>(a + i * VEC, u);
+        load_f<T, VEC>(b + i * VEC, v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) u[k] += v[k];
+        store_f<T, VEC>(y + i * VEC, u);
+    }
+}
+
+template <typename T>
+static int launch_affine_fwd(const void* x, const void* res, void* y, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
+                             int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW, const float* A,
+                             const float* S, int cpi, int relu, hipStream_t st) {
+    RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, tabH, tabW};
+    const int ly = lines_per_image(B, Ho);
+    dim3 grid((unsigned)(B * ly));
+    const bool vec_ok = pick_vec<T>(C) > 1 && (!x || aligned16(x)) && aligned16(y) && (!res || aligned16(res)) &&
+                        (!A || aligned16(A)) && (!S || aligned16(S));
+    if (vec_ok)
+        hipLaunchKernelGGL((affine_fwd_kernel<T, FullVec<T>::value>), grid, dim3(kThreads), 0, st, (const T*)x,
+                           (const T*)res, (T*)y, g, ly, A, S, cpi, relu);
+    else
+        hipLaunchKernelGGL((affine_fwd_kernel<T, 1>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)res, (T*)y, g,
+                           ly, A, S, cpi, relu);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int launch_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t B, int64_t Ho,
+                             int64_t Wo, int64_t C, int64_t Hs, int64_t Ws, const int32_t* invH, const int32_t* invW,
+                             const float* P, const float* Q, const float* R, int cpi, hipStream_t st) {
+    RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, nullptr, nullptr};
+    const int ly = lines_per_image(B, Hs);
+    dim3 grid((unsigned)(B * ly));
+    const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(dy) && aligned16(dx) && (!x || aligned16(x)) &&
+                        (!y || aligned16(y)) && (!dres || aligned16(dres)) && (!P || aligned16(P)) &&
+                        (!Q || aligned16(Q)) && (!R || aligned16(R));
+    if (vec_ok)
+        hipLaunchKernelGGL((affine_bwd_kernel<T, FullVec<T>::value>), grid, dim3(kThreads), 0, st, (const T*)dy,
+                           (const T*)x, (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, cpi);
+    else
+        hipLaunchKernelGGL((affine_bwd_kernel<T, 1>), grid, dim3(kThreads), 0, st, (const T*)dy, (const T*)x,
+                           (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, cpi);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int launch_add(const void* a, const void* b, void* y, int64_t n, hipStream_t st) {
+    const int full = FullVec<T>::value;
+    const bool vec_ok = n % full == 0 && aligned16(a) && aligned16(b) && aligned16(y);
+    const int64_t nvec = vec_ok ? n / full : n;
+    int64_t blocks = (nvec + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (vec_ok)
+        hipLaunchKernelGGL((add_kernel<T, FullVec<T>::value>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T*)a, (const T*)b, (T*)y, nvec);
+    else
+        hipLaunchKernelGGL((add_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, (const T*)a, (const T*)b,
+                           (T*)y, nvec);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mrfp
+
+using namespace mrfp;
+
+extern "C" {
+
+int mrfp_affine_fwd(const void* x, const void* res, void* y, int dtype, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
+                    int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW, const float* A, const float* S,
+                    int coef_per_image, int relu, void* stream) {
+    MRFP_CHECK(y && B > 0 && Ho > 0 && Wo > 0 && C > 0 && Hs > 0 && Ws > 0, "affine_fwd: bad arguments");
+    MRFP_CHECK(x || S, "affine_fwd: neither x nor S given");
+    MRFP_CHECK((tabH && tabW) || (Hs == Ho && Ws == Wo), "affine_fwd: resize geometry without index tables");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return launch_affine_fwd<float>(x, res, y, B, Ho, Wo, C, Hs, Ws, tabH, tabW, A, S, coef_per_image, relu, st);
+    if (dtype == MRFP_BF16) return launch_affine_fwd<bf16>(x, res, y, B, Ho, Wo, C, Hs, Ws, tabH, tabW, A, S, coef_per_image, relu, st);
+    MRFP_CHECK(false, "affine_fwd: unknown dtype %d", dtype);
+}
+
+int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int dtype, int64_t B,
+                    int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws, const int32_t* invH, const int32_t* invW,
+                    const float* P, const float* Q, const float* R, int coef_per_image, void* stream) {
+    MRFP_CHECK(dy && dx && B > 0 && Ho > 0 && Wo > 0 && C > 0 && Hs > 0 && Ws > 0, "affine_bwd: bad arguments");
+    MRFP_CHECK((invH && invW) || (Hs == Ho && Ws == Wo), "affine_bwd: resize geometry without inverse tables");
+    MRFP_CHECK(!dres || (!invH && !invW), "affine_bwd: dres is not supported behind a resize");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return launch_affine_bwd<float>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, coef_per_image, st);
+    if (dtype == MRFP_BF16) return launch_affine_bwd<bf16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, coef_per_image, st);
+    MRFP_CHECK(false, "affine_bwd: unknown dtype %d", dtype);
+}
+
+int mrfp_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream) {
+    MRFP_CHECK(a && b && y && n > 0, "add: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return launch_add<float>(a, b, y, n, st);
+    if (dtype == MRFP_BF16) return launch_add<bf16>(a, b, y, n, st);
+    MRFP_CHECK(false, "add: unknown dtype %d", dtype);
+}
+
+}  // extern "C"

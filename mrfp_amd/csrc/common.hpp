@@ -1,0 +1,119 @@
+// common.hpp -- shared device helpers for libmrfp_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mrfp_hip.h"
+
+namespace mrfp {
+
+void set_error(const char* fmt, ...);
+
+#define MRFP_CHECK(cond, ...)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            ::mrfp::set_error(__VA_ARGS__);        \
+            return -1;                             \
+        }                                          \
+    } while (0)
+
+#define MRFP_LAUNCH_CHECK()                                                   \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            ::mrfp::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,  \
+                              hipGetErrorString(e__));                        \
+            return -2;                                                        \
+        }                                                                     \
+    } while (0)
+
+typedef __hip_bfloat16 bf16;
+
+// ---- element <-> float ----------------------------------------------------------------------
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __float2bfloat16(v); }
+
+// ---- 16-byte vectors of VEC elements ---------------------------------------------------------
+// VecT<T,VEC>: VEC elements moved with ONE memory instruction when VEC*sizeof(T) == 16
+// (float x4, bf16 x8); VEC == 1 is the scalar tail path for odd channel counts (C = 19).
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
+
+template <typename T> struct FullVec { static constexpr int value = 16 / sizeof(T); };
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_f(const T* p, float (&out)[VEC]) {
+    VecT<T, VEC> t = *reinterpret_cast<const VecT<T, VEC>*>(p);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = to_f(t.v[i]);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_f(T* p, const float (&in)[VEC]) {
+    VecT<T, VEC> t;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) t.v[i] = from_f<T>(in[i]);
+    *reinterpret_cast<VecT<T, VEC>*>(p) = t;
+}
+template <int VEC>
+__device__ __forceinline__ void load_coef(const float* p, float (&out)[VEC]) {
+    VecT<float, VEC> t = *reinterpret_cast<const VecT<float, VEC>*>(p);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = t.v[i];
+}
+
+// ---- reductions -------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Geometry of a "row kernel": one workgroup walks destination lines (b, oh) of a [B,Ho,Wo,C]
+// tensor; 256 threads are laid out as (rowthreads x colthreads) over (ow, channel-vector).
+struct RowGeom {
+    int B, Ho, Wo, C, Hs, Ws;
+    const int32_t* tabH;
+    const int32_t* tabW;
+};
+
+constexpr int kThreads = 256;
+
+struct Lanes {
+    int lpr;         // channel vectors per row = C / VEC
+    int colthreads;  // threads across the channel dimension
+    int rowthreads;  // threads across pixels of a line
+};
+__host__ __device__ inline Lanes make_lanes(int C, int VEC) {
+    Lanes l;
+    l.lpr = C / VEC;
+    l.colthreads = l.lpr < kThreads ? l.lpr : kThreads;
+    l.rowthreads = kThreads / l.colthreads;
+    return l;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// choose the vector width for a channel count: full 16-byte vectors when C allows it
+template <typename T> inline int pick_vec(int64_t C) {
+    const int full = FullVec<T>::value;
+    return (C % full == 0) ? full : 1;
+}
+
+inline int lines_per_image(int64_t B, int64_t Ho) {
+    // ~4096 workgroups in flight over the chip (256 CUs x 8 XCDs): enough to hide HBM latency,
+    // few enough that the partial-sum workspace stays a fraction of a percent of the tensor.
+    int64_t cap = 4096 / (B > 0 ? B : 1);
+    if (cap < 1) cap = 1;
+    return (int)(Ho < cap ? Ho : cap);
+}
+
+}  // namespace mrfp

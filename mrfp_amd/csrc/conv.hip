@@ -1,0 +1,603 @@
+// conv.hip -- implicit-GEMM convolution on the gfx950 matrix cores (MFMA), NHWC activations.
+//
+//   forward :  Y[m, n]  = sum_{r,s,c} X[pix(m; r,s), c] * Wf[n, (r,s,c)]         m = (b, oh, ow)
+//   dgrad   :  the same kernel on dY with the flipped/transposed pack Wd[c, (r',s',n)] and a
+//              "source stride" for strided convolutions (a tap exists only where the position
+//              divides the stride)
+//
+// Tiling (one workgroup = WM x WN waves, every wave owns a 64x64 output tile = 2x2 MFMA 32x32
+// accumulators): the K dimension is walked in 128-BYTE steps (64 bf16 / 32 fp32 = 8 chunks of
+// 16 bytes).  A chunk never straddles an (r,s) tap because the channel count is a multiple of
+// the chunk, so every 16-byte global load is either a contiguous run of input channels of one
+// pixel or zero (padding) -- im2col happens in the address computation, the matrix is never
+// materialised.  Tiles are staged global -> registers -> LDS (double buffered: the loads of tile
+// k+1 are in flight while tile k is multiplied), LDS rows are 128 B with the 16-byte slot XOR-
+// swizzled by (row>>1)&7 so that the ds_read_b128 fragment reads are bank-conflict free.
+//
+//   bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate)       -- bench dtype
+//   fp32: v_mfma_f32_32x32x2_f32   (exact fp32 FMA chains)  -- parity dtype
+// Both share the byte geometry, so there is one kernel template.
+//
+// Replaces (reference): every nn.Conv2d on the hot path -- Resnet.py:156-161 (Bottleneck),
+// deepv3.py:96-112 (ASPP), 200-219 (decoder), 221-237 (HRFP), and their autograd backward.
+#include "common.hpp"
+
+namespace mrfp {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+struct ConvP {
+    const char* x;      // source activation [B,H,W,C]
+    const char* w;      // packed weight [N][kchunks] 16-byte chunks
+    char* y;            // output [M][ldy]
+    const float* bias;  // [N] or null
+    int B, H, W, C;
+    int N, ldy;
+    int R, S, Ho, Wo;
+    int stride, pad_h, pad_w, dil, sstride;
+    int M, cpr, kchunks;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // the 16-byte fragment holds 4 consecutive k of one row; MFMA j pairs k = 8q+j (lanes 0-31)
+    // with k = 8q+4+j (lanes 32-63) -- the same pairing for A and B, so the sum over k is complete.
+    static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+// XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): consecutive logical tiles
+// land on the same XCD so the tiles sharing an activation panel hit one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <typename T, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
+    constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
+    constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sA0 = smem;
+    char* const sB0 = smem + BM * 128;
+    constexpr int BUF = (BM + BN) * 128;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int chunk = t & 7, rbase = t >> 3;
+
+    // fixed per-thread gather state for its SA rows of the A tile
+    int a_ih0[SA], a_iw0[SA];
+    const char* a_img[SA];
+#pragma unroll
+    for (int i = 0; i < SA; ++i) {
+        const int m = m0 + rbase + i * RSTEP;
+        if (m < p.M) {
+            const int b = m / (p.Ho * p.Wo), rem = m - b * (p.Ho * p.Wo);
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            a_ih0[i] = oh * p.stride - p.pad_h;
+            a_iw0[i] = ow * p.stride - p.pad_w;
+            a_img[i] = p.x + (size_t)b * p.H * p.W * p.C * sizeof(T);
+        } else {
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = 0;
+            a_img[i] = p.x;
+        }
+    }
+    const int pixbytes = p.C * (int)sizeof(T);
+
+    auto load_tile = [&](int kt, uint4 (&ra)[SA], uint4 (&rb)[SB]) {
+        const int q = kt * 8 + chunk;
+        const int rs = q / p.cpr, cc = q - rs * p.cpr;
+        const int r = rs / p.S, s = rs - r * p.S;
+        const bool qok = q < p.kchunks;
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            int ih = a_ih0[i] + r * p.dil, iw = a_iw0[i] + s * p.dil;
+            bool ok = qok && ih >= 0 && iw >= 0;
+            if (p.sstride > 1) {
+                ok = ok && (ih % p.sstride == 0) && (iw % p.sstride == 0);
+                ih /= p.sstride;
+                iw /= p.sstride;
+            }
+            ok = ok && ih < p.H && iw < p.W;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *reinterpret_cast<const uint4*>(a_img[i] + (size_t)(ih * p.W + iw) * pixbytes + cc * 16);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int n = n0 + rbase + i * RSTEP;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qok && n < p.N) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)n * p.kchunks + q) * 16);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf, const uint4 (&ra)[SA], const uint4 (&rb)[SB]) {
+        char* a = sA0 + buf * BUF;
+        char* b = sB0 + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < SA; ++i) *reinterpret_cast<uint4*>(a + lds_off(rbase + i * RSTEP, chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) *reinterpret_cast<uint4*>(b + lds_off(rbase + i * RSTEP, chunk)) = rb[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nkt = (p.kchunks + 7) >> 3;
+    uint4 ra[SA], rb[SB];
+    load_tile(0, ra, rb);
+    store_tile(0, ra, rb);
+    __syncthreads();
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1, ra, rb);
+        const char* a = sA0 + buf * BUF;
+        const char* b = sB0 + buf * BUF;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = kk * 2 + lh;
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const uint4*>(a + lds_off(wm * 64 + i * 32 + lr, ch));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 64 + j * 32 + lr, ch));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1, ra, rb);
+        __syncthreads();
+    }
+
+    // epilogue: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+    T* y = reinterpret_cast<T*>(p.y);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + lr;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.M) y[(size_t)m * p.ldy + n] = from_f<T>(acc[i][j][e] + bv);
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int WN>
+static int launch_igemm(const ConvP& p, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int lds = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, st, p);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int run_igemm(const ConvP& p, hipStream_t st) {
+    if (p.N <= 64) return launch_igemm<T, 4, 1>(p, st);
+    return launch_igemm<T, 2, 2>(p, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: OIHW fp32 master  ->  forward pack Wf[Npad][R][S][Cpad]  (T)
+//                                   ->  dgrad   pack Wd[Cin][R][S][Npad] with taps flipped (T)
+// (pad channels are zero).  One thread per destination element.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int N, int C,
+                                   int R, int S, int Npad, int Cpad) {
+    const int64_t nf = (int64_t)Npad * R * S * Cpad, nd = (int64_t)C * R * S * Npad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            if (!wf) continue;
+            const int c = (int)(i % Cpad);
+            int64_t rest = i / Cpad;
+            const int s = (int)(rest % S); rest /= S;
+            const int r = (int)(rest % R);
+            const int n = (int)(rest / R);
+            const float v = (n < N && c < C) ? w[(((int64_t)n * C + c) * R + r) * S + s] : 0.f;
+            wf[i] = from_f<T>(v);
+        } else {
+            if (!wd) continue;
+            const int64_t k = i - nf;
+            const int n = (int)(k % Npad);
+            int64_t rest = k / Npad;
+            const int s = (int)(rest % S); rest /= S;
+            const int r = (int)(rest % R);
+            const int c = (int)(rest / R);
+            const float v = (n < N) ? w[(((int64_t)n * C + c) * R + (R - 1 - r)) * S + (S - 1 - s)] : 0.f;
+            wd[k] = from_f<T>(v);
+        }
+    }
+}
+
+// network input: NCHW fp32 [B,C,H,W] -> NHWC T [B,H,W,Cpad] (pad channels zero)
+template <typename T>
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int H, int W, int Cpad) {
+    const int64_t npix = (int64_t)B * H * W;
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = pix / ((int64_t)H * W), hw = pix % ((int64_t)H * W);
+        for (int c = 0; c < Cpad; ++c) {
+            const float v = c < C ? x[(b * C + c) * (int64_t)H * W + hw] : 0.f;
+            y[pix * Cpad + c] = from_f<T>(v);
+        }
+    }
+}
+
+}  // namespace mrfp
+
+using namespace mrfp;
+
+extern "C" {
+
+int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
+                  int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
+                  int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, void* stream) {
+    MRFP_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
+               "conv_fwd: bad arguments");
+    MRFP_CHECK(stride >= 1 && dil >= 1 && sstride >= 1 && ldy >= N, "conv_fwd: bad stride/dilation/pitch");
+    const int esz = dtype == MRFP_F32 ? 4 : 2;
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "conv_fwd: unknown dtype %d", dtype);
+    MRFP_CHECK((C * esz) % 16 == 0, "conv_fwd: C=%lld must make 16-byte chunks (pad the channels)", (long long)C);
+    MRFP_CHECK(aligned16(x) && aligned16(wpack), "conv_fwd: x / wpack must be 16-byte aligned");
+    MRFP_CHECK(B * Ho * Wo < (1LL << 31) && H * W * C * esz < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
+    ConvP p;
+    p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias;
+    p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
+    p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
+    p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
+    p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    if (dtype == MRFP_F32) return run_igemm<float>(p, (hipStream_t)stream);
+    return run_igemm<bf16>(p, (hipStream_t)stream);
+}
+
+int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, int64_t C, int64_t R, int64_t S,
+                     int64_t Npad, int64_t Cpad, void* stream) {
+    MRFP_CHECK(w && (wf || wd) && N > 0 && C > 0 && R > 0 && S > 0 && Npad >= N && Cpad >= C, "pack_weight: bad arguments");
+    const int64_t total = Npad * R * S * Cpad + C * R * S * Npad;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == MRFP_F32)
+        hipLaunchKernelGGL((pack_weight_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                           (float*)wf, (float*)wd, (int)N, (int)C, (int)R, (int)S, (int)Npad, (int)Cpad);
+    else if (dtype == MRFP_BF16)
+        hipLaunchKernelGGL((pack_weight_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                           (bf16*)wf, (bf16*)wd, (int)N, (int)C, (int)R, (int)S, (int)Npad, (int)Cpad);
+    else
+        MRFP_CHECK(false, "pack_weight: unknown dtype %d", dtype);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_nchw_to_nhwc_pad(const float* x, void* y, int dtype, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cpad,
+                          void* stream) {
+    MRFP_CHECK(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc_pad: bad arguments");
+    int64_t blocks = (B * H * W + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == MRFP_F32)
+        hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                           (float*)y, (int)B, (int)C, (int)H, (int)W, (int)Cpad);
+    else if (dtype == MRFP_BF16)
+        hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                           (bf16*)y, (int)B, (int)C, (int)H, (int)W, (int)Cpad);
+    else
+        MRFP_CHECK(false, "nchw_to_nhwc_pad: unknown dtype %d", dtype);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// wgrad:  dW[n, (r,s,c)] = sum_m dY[m, n] * X[pix(m; r,s), c]          (reduction over pixels)
+//
+// GEMM with M' = output channels, N' = R*S*C, K' = B*Ho*Wo.  Both operands are stored with the
+// reduction index (the pixel) as the SLOW dimension, i.e. they are "k-strided": the LDS tiles
+// keep the natural [pixel][channel] layout (filled with 16-byte loads along the channels) and the
+// MFMA fragments are formed with the gfx950 transposing LDS read ds_read_b64_tr_b16 (bf16) or
+// with plain strided ds_read_b32 (fp32).  Row pitch = row bytes + 64 so that the four pixel rows
+// of one transposed read fall into four disjoint 16-bank windows.
+// K' is split over gridDim.y workgroups; every split writes an fp32 slab, a second kernel sums
+// the slabs in a fixed order (bitwise reproducible) and emits the OIHW fp32 gradient.
+// =============================================================================================
+namespace mrfp {
+
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((address_space(3))) short4v lds_short4v;
+
+struct WgP {
+    const char* x;    // [B,H,W,C]
+    const char* dy;   // [M][ldn]
+    float* slab;      // [splits][N][Q]
+    int B, H, W, C;
+    int N, ldn;       // logical output channels, physical pitch of dy (elements)
+    int R, S, Ho, Wo, stride, pad_h, pad_w, dil;
+    int M, Q;         // pixels, R*S*C
+    int klen;         // pixels per split (multiple of 32)
+};
+
+template <typename T> struct WgFrag;
+template <> struct WgFrag<bf16> {
+    // 32(rows along the lane) x 16(k) operand from a [pixel][channel] tile; col0 = first channel of
+    // the 32-column block, krow0 = first pixel row of this 16-deep k step
+    static __device__ __forceinline__ uint4 read(const char* tile, int pitch, int col0, int krow0, int lane) {
+        const int g = lane >> 4;
+        const int col = col0 + 16 * (g & 1) + 4 * (lane & 3);
+        const int row = krow0 + 8 * (g >> 1) + ((lane & 15) >> 2);
+        const char* p0 = tile + row * pitch + col * 2;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v*)(p0));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v*)(p0 + 4 * pitch));
+        uint4 r;
+        r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+        r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+        r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+        r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+        return r;
+    }
+    static constexpr int KSTEP = 16;   // pixels consumed per Mma<bf16>::run
+};
+template <> struct WgFrag<float> {
+    // 4 MFMA 32x32x2 per call: element j of lane-half h is pixel krow0 + 2*j + h
+    static __device__ __forceinline__ uint4 read(const char* tile, int pitch, int col0, int krow0, int lane) {
+        const int c = col0 + (lane & 31), h = lane >> 5;
+        uint4 r;
+        r.x = *reinterpret_cast<const unsigned*>(tile + (krow0 + 0 + h) * pitch + c * 4);
+        r.y = *reinterpret_cast<const unsigned*>(tile + (krow0 + 2 + h) * pitch + c * 4);
+        r.z = *reinterpret_cast<const unsigned*>(tile + (krow0 + 4 + h) * pitch + c * 4);
+        r.w = *reinterpret_cast<const unsigned*>(tile + (krow0 + 6 + h) * pitch + c * 4);
+        return r;
+    }
+    static constexpr int KSTEP = 8;
+};
+
+template <typename T, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BKP = 32;                                  // pixels per K' tile
+    constexpr int EPC = 16 / (int)sizeof(T);                 // elements per 16-byte chunk
+    constexpr int CY = 64 * WM / EPC, CX = 64 * WN / EPC;    // chunks per tile row
+    constexpr int SY = BKP * CY / 256, SX = BKP * CX / 256;  // slots per thread
+    constexpr int PY = 64 * WM * (int)sizeof(T) + 64, PX = 64 * WN * (int)sizeof(T) + 64;   // row pitches
+    constexpr int BUF = BKP * (PY + PX);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntq = (p.Q + 64 * WN - 1) / (64 * WN);
+    const int n0 = (blockIdx.x / ntq) * 64 * WM, q0 = (blockIdx.x % ntq) * 64 * WN;
+    const int kbeg = blockIdx.y * p.klen;
+    const int kend = min(p.M, kbeg + p.klen);
+
+    // dY slots: dense rows
+    const int ychunk = t % CY, yrow = t / CY;
+    const int yn = n0 + ychunk * EPC;
+    const bool yok = yn < p.ldn;
+    // X slots: fixed tap/channel per thread, moving pixel per slot
+    const int xchunk = t % CX, xrow = t / CX;
+    const int q = q0 + xchunk * EPC;
+    const bool qok = q < p.Q;
+    const int rs = q / p.C, c = q - rs * p.C;
+    const int r = rs / p.S, s = rs - r * p.S;
+    int xb[SX], xoh[SX], xow[SX];
+#pragma unroll
+    for (int i = 0; i < SX; ++i) {
+        const int m = kbeg + xrow + i * (256 / CX);
+        xb[i] = m / (p.Ho * p.Wo);
+        const int rem = m - xb[i] * (p.Ho * p.Wo);
+        xoh[i] = rem / p.Wo;
+        xow[i] = rem - xoh[i] * p.Wo;
+    }
+    const int pixbytes = p.C * (int)sizeof(T);
+
+    auto load_tile = [&](int k0, uint4 (&ry)[SY], uint4 (&rx)[SX]) {
+#pragma unroll
+        for (int i = 0; i < SY; ++i) {
+            const int m = k0 + yrow + i * (256 / CY);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yok && m < kend) v = *reinterpret_cast<const uint4*>(p.dy + ((size_t)m * p.ldn + yn) * sizeof(T));
+            ry[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            const int m = k0 + xrow + i * (256 / CX);
+            const int ih = xoh[i] * p.stride - p.pad_h + r * p.dil, iw = xow[i] * p.stride - p.pad_w + s * p.dil;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qok && m < kend && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(xb[i] * p.H + ih) * p.W + iw) * pixbytes + c * sizeof(T));
+            rx[i] = v;
+            // advance this slot's pixel by one K' tile
+            xow[i] += BKP;
+            while (xow[i] >= p.Wo) {
+                xow[i] -= p.Wo;
+                if (++xoh[i] == p.Ho) { xoh[i] = 0; ++xb[i]; }
+            }
+        }
+    };
+    auto store_tile = [&](int buf, const uint4 (&ry)[SY], const uint4 (&rx)[SX]) {
+        char* ty = smem + buf * BUF;
+        char* tx = ty + BKP * PY;
+#pragma unroll
+        for (int i = 0; i < SY; ++i) *reinterpret_cast<uint4*>(ty + (yrow + i * (256 / CY)) * PY + ychunk * 16) = ry[i];
+#pragma unroll
+        for (int i = 0; i < SX; ++i) *reinterpret_cast<uint4*>(tx + (xrow + i * (256 / CX)) * PX + xchunk * 16) = rx[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nkt = (kend - kbeg + BKP - 1) / BKP;
+    uint4 ry[SY], rx[SX];
+    if (nkt > 0) {
+        load_tile(kbeg, ry, rx);
+        store_tile(0, ry, rx);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BKP, ry, rx);
+        const char* ty = smem + buf * BUF;
+        const char* tx = ty + BKP * PY;
+#pragma unroll
+        for (int ks = 0; ks < BKP / WgFrag<T>::KSTEP; ++ks) {
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = WgFrag<T>::read(ty, PY, wm * 64 + i * 32, ks * WgFrag<T>::KSTEP, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = WgFrag<T>::read(tx, PX, wn * 64 + j * 32, ks * WgFrag<T>::KSTEP, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1, ry, rx);
+        __syncthreads();
+    }
+
+    float* out = p.slab + (size_t)blockIdx.y * p.N * p.Q;
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qq = q0 + wn * 64 + j * 32 + lr;
+        if (qq >= p.Q) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (n < p.N) out[(size_t)n * p.Q + qq] = acc[i][j][e];
+            }
+    }
+}
+
+// dW[n][c][r][s] (OIHW fp32, c < Ctrue) = sum_z slab[z][n][(r*S+s)*C + c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int N, int Q, int C, int Ctrue, int R,
+                                    int S, float* __restrict__ dw) {
+    const int64_t total = (int64_t)N * Ctrue * R * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % S);
+        int64_t rest = i / S;
+        const int r = (int)(rest % R); rest /= R;
+        const int c = (int)(rest % Ctrue);
+        const int n = (int)(rest / Ctrue);
+        const size_t src = (size_t)n * Q + (size_t)(r * S + s) * C + c;
+        float acc = 0.f;
+        for (int z = 0; z < splits; ++z) acc += slab[(size_t)z * N * Q + src];
+        dw[i] = acc;
+    }
+}
+
+template <typename T, int WM, int WN>
+static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
+    constexpr int PY = 64 * WM * (int)sizeof(T) + 64, PX = 64 * WN * (int)sizeof(T) + 64;
+    const int lds = 2 * 32 * (PY + PX);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = ((p.N + 64 * WM - 1) / (64 * WM)) * ((p.Q + 64 * WN - 1) / (64 * WN));
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, p);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int& wm, int& splits, int& klen) {
+    wm = N <= 64 ? 1 : 2;
+    const int wn = 4 / wm;
+    const int64_t tiles = ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
+    const int64_t nkt = (M + 31) / 32;
+    int64_t sp = 2048 / tiles;
+    if (sp < 1) sp = 1;
+    if (sp > nkt) sp = nkt;
+    int64_t per = (nkt + sp - 1) / sp;        // K' tiles per split
+    sp = (nkt + per - 1) / per;
+    splits = (int)sp;
+    klen = (int)(per * 32);
+}
+
+}  // namespace mrfp
+
+extern "C" {
+
+int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q) {
+    int wm, splits, klen;
+    mrfp::wgrad_plan(M, N, Q, wm, splits, klen);
+    return (int64_t)splits * N * Q * 4;
+}
+
+int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype, int64_t B, int64_t H, int64_t W,
+                    int64_t C, int64_t Ctrue, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
+                    int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, void* stream) {
+    MRFP_CHECK(x && dy && dw && ws && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
+               "conv_wgrad: bad arguments");
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "conv_wgrad: unknown dtype %d", dtype);
+    const int esz = dtype == MRFP_F32 ? 4 : 2;
+    MRFP_CHECK((C * esz) % 16 == 0 && (ldn * esz) % 16 == 0 && ldn >= N && Ctrue <= C,
+               "conv_wgrad: channel counts must make 16-byte chunks (C=%lld ldn=%lld)", (long long)C, (long long)ldn);
+    MRFP_CHECK(aligned16(x) && aligned16(dy), "conv_wgrad: x / dy must be 16-byte aligned");
+    MRFP_CHECK(B * Ho * Wo < (1LL << 31) && B * H * W * C * esz < (1LL << 40), "conv_wgrad: tensor too large");
+    WgP p;
+    p.x = (const char*)x; p.dy = (const char*)dy; p.slab = (float*)ws;
+    p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldn = (int)ldn;
+    p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
+    p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil;
+    p.M = (int)(B * Ho * Wo); p.Q = (int)(R * S * C);
+    int wm, splits;
+    wgrad_plan(p.M, N, p.Q, wm, splits, p.klen);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st) : launch_wgrad<float, 2, 2>(p, splits, st);
+    else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st) : launch_wgrad<bf16, 2, 2>(p, splits, st);
+    if (rc) return rc;
+    const int64_t total = N * Ctrue * R * S;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, splits, (int)N,
+                       p.Q, (int)C, (int)Ctrue, (int)R, (int)S, dw);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// resize_pool.hip -- bilinear (align_corners=True) resize fwd/bwd and MaxPool2d(3,2,1) fwd/bwd, NHWC.
+// Both backward kernels are written in GATHER form (walk the gradient of the input, sum the
+// contributions of the few outputs that touch it): no atomics, bitwise reproducible.
+//
+// Replaces (reference): Upsample() = F.interpolate(mode='bilinear', align_corners=True)
+// (mynn.py:114-119; call sites deepv3.py:121, 351, 356, 361) and nn.MaxPool2d(3, 2, 1)
+// (Resnet.py:551, deepv3.py:315).
+#include "common.hpp"
+
+namespace mrfp {
+
+// ATen: scale = (in-1)/(out-1) in float (0 when out == 1); src = scale*dst; i0 = (int)src;
+// lambda1 = src - i0; i1 = i0 + (i0 < in-1)
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap ac_tap(float scale, int dst, int in) {
+    const float src = scale * (float)dst;
+    Tap t;
+    t.i0 = (int)src;
+    t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+    t.l1 = src - (float)t.i0;
+    t.l0 = 1.f - t.l1;
+    return t;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(const T* __restrict__ x, const T* __restrict__ addend,
+                                                                T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo,
+                                                                int C, int ldi, int ly) {
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    if (trow >= L.rowthreads) return;
+    const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+    for (int cv = tcol; cv < L.lpr; cv += kThreads) {
+        for (int oh = j; oh < Ho; oh += ly) {
+            const Tap th = ac_tap(sh, oh, Hi);
+            const T* r0 = x + ((size_t)b * Hi + th.i0) * Wi * ldi + (size_t)cv * VEC;
+            const T* r1 = x + ((size_t)b * Hi + th.i1) * Wi * ldi + (size_t)cv * VEC;
+            const size_t dl = ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
+            for (int ow = trow; ow < Wo; ow += L.rowthreads) {
+                const Tap tw = ac_tap(sw, ow, Wi);
+                float a[VEC], bb[VEC], c[VEC], d[VEC], o[VEC];
+                load_f<T, VEC>(r0 + (size_t)tw.i0 * ldi, a);
+                load_f<T, VEC>(r0 + (size_t)tw.i1 * ldi, bb);
+                load_f<T, VEC>(r1 + (size_t)tw.i0 * ldi, c);
+                load_f<T, VEC>(r1 + (size_t)tw.i1 * ldi, d);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    o[i] = th.l0 * (tw.l0 * a[i] + tw.l1 * bb[i]) + th.l1 * (tw.l0 * c[i] + tw.l1 * d[i]);
+                if (addend) {
+                    float e[VEC];
+                    load_f<T, VEC>(addend + dl + (size_t)ow * C, e);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o[i] += e[i];
+                }
+                store_f<T, VEC>(y + dl + (size_t)ow * C, o);
+            }
+        }
+    }
+}
+
+// weight with which destination index `dst` reads source index `src`
+__device__ __forceinline__ float ac_weight(float scale, int dst, int in, int src) {
+    const Tap t = ac_tap(scale, dst, in);
+    return (t.i0 == src ? t.l0 : 0.f) + (t.i1 == src ? t.l1 : 0.f);
+}
+// candidate destination range that can touch source index `src` (one index of slack on both sides)
+__device__ __forceinline__ void ac_range(float scale, int src, int out, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    lo = (int)floorf((float)(src - 1) / scale) - 1;
+    hi = (int)ceilf((float)(src + 1) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
+                                                                int Hi, int Wi, int Ho, int Wo, int C, int ldi, int ly) {
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    if (trow >= L.rowthreads) return;
+    const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+    for (int cv = tcol; cv < L.lpr; cv += kThreads) {
+        for (int ih = j; ih < Hi; ih += ly) {
+            int oh0, oh1;
+            ac_range(sh, ih, Ho, oh0, oh1);
+            for (int iw = trow; iw < Wi; iw += L.rowthreads) {
+                int ow0, ow1;
+                ac_range(sw, iw, Wo, ow0, ow1);
+                float acc[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                for (int oh = oh0; oh <= oh1; ++oh) {
+                    const float wh = ac_weight(sh, oh, Hi, ih);
+                    if (wh == 0.f) continue;
+                    const T* dl = dy + ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
+                    for (int ow = ow0; ow <= ow1; ++ow) {
+                        const float w = wh * ac_weight(sw, ow, Wi, iw);
+                        if (w == 0.f) continue;
+                        float dv[VEC];
+                        load_f<T, VEC>(dl + (size_t)ow * C, dv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] += w * dv[i];
+                    }
+                }
+                store_f<T, VEC>(dx + (((size_t)b * Hi + ih) * Wi + iw) * ldi + (size_t)cv * VEC, acc);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                               uint8_t* __restrict__ idx, int B, int H, int W, int Ho,
+                                                               int Wo, int C, int ly) {
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    if (trow >= L.rowthreads) return;
+    for (int cv = tcol; cv < L.lpr; cv += kThreads) {
+        for (int oh = j; oh < Ho; oh += ly) {
+            for (int ow = trow; ow < Wo; ow += L.rowthreads) {
+                float best[VEC];
+                uint8_t bi[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int ih = 2 * oh - 1 + r;
+                    if (ih < 0 || ih >= H) continue;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const int iw = 2 * ow - 1 + s;
+                        if (iw < 0 || iw >= W) continue;
+                        float v[VEC];
+                        load_f<T, VEC>(x + (((size_t)b * H + ih) * W + iw) * C + (size_t)cv * VEC, v);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bi[i] = (uint8_t)(r * 3 + s); }
+                    }
+                }
+                const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C + (size_t)cv * VEC;
+                store_f<T, VEC>(y + o, best);
+                VecT<uint8_t, VEC> pk;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) pk.v[i] = bi[i];
+                *reinterpret_cast<VecT<uint8_t, VEC>*>(idx + o) = pk;
+            }
+        }
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                               T* __restrict__ dx, int B, int H, int W, int Ho, int Wo,
+                                                               int C, int ly) {
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    if (trow >= L.rowthreads) return;
+    for (int cv = tcol; cv < L.lpr; cv += kThreads) {
+        for (int ih = j; ih < H; ih += ly) {
+            const int oh0 = ih / 2, oh1 = (ih + 1) / 2;   // windows 2*oh-1 .. 2*oh+1 containing ih
+            for (int iw = trow; iw < W; iw += L.rowthreads) {
+                const int ow0 = iw / 2, ow1 = (iw + 1) / 2;
+                float acc[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                for (int oh = oh0; oh <= oh1; ++oh) {
+                    if (oh >= Ho) continue;
+                    const int r = ih - (2 * oh - 1);
+                    for (int ow = ow0; ow <= ow1; ++ow) {
+                        if (ow >= Wo) continue;
+                        const int s = iw - (2 * ow - 1);
+                        const uint8_t want = (uint8_t)(r * 3 + s);
+                        const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C + (size_t)cv * VEC;
+                        const VecT<uint8_t, VEC> pk = *reinterpret_cast<const VecT<uint8_t, VEC>*>(idx + o);
+                        float dv[VEC];
+                        load_f<T, VEC>(dy + o, dv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] += pk.v[i] == want ? dv[i] : 0.f;
+                    }
+                }
+                store_f<T, VEC>(dx + (((size_t)b * H + ih) * W + iw) * C + (size_t)cv * VEC, acc);
+            }
+        }
+    }
+}
+
+#define DISPATCH_VEC(T, C, ok, KERNEL, grid, st, ...)                                                      \
+    do {                                                                                                   \
+        if (pick_vec<T>(C) > 1 && (ok))                                                                    \
+            hipLaunchKernelGGL((KERNEL<T, FullVec<T>::value>), grid, dim3(kThreads), 0, st, __VA_ARGS__);  \
+        else                                                                                               \
+            hipLaunchKernelGGL((KERNEL<T, 1>), grid, dim3(kThreads), 0, st, __VA_ARGS__);                  \
+        MRFP_LAUNCH_CHECK();                                                                               \
+    } while (0)
+
+template <typename T>
+static int do_bilinear_fwd(const void* x, const void* addend, void* y, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho,
+                           int64_t Wo, int64_t C, int64_t ldi, hipStream_t st) {
+    const int ly = lines_per_image(B, Ho);
+    const bool ok = aligned16(x) && aligned16(y) && (!addend || aligned16(addend)) && ldi % FullVec<T>::value == 0;
+    DISPATCH_VEC(T, C, ok, bilinear_fwd_kernel, dim3((unsigned)(B * ly)), st, (const T*)x, (const T*)addend, (T*)y,
+                 (int)B, (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly);
+    return 0;
+}
+template <typename T>
+static int do_bilinear_bwd(const void* dy, void* dx, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
+                           int64_t C, int64_t ldi, hipStream_t st) {
+    const int ly = lines_per_image(B, Hi);
+    const bool ok = aligned16(dy) && aligned16(dx) && ldi % FullVec<T>::value == 0;
+    DISPATCH_VEC(T, C, ok, bilinear_bwd_kernel, dim3((unsigned)(B * ly)), st, (const T*)dy, (T*)dx, (int)B, (int)Hi,
+                 (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly);
+    return 0;
+}
+template <typename T>
+static int do_maxpool_fwd(const void* x, void* y, uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C,
+                          hipStream_t st) {
+    const int Ho = (int)((H + 2 - 3) / 2 + 1), Wo = (int)((W + 2 - 3) / 2 + 1);
+    const int ly = lines_per_image(B, Ho);
+    const bool ok = aligned16(x) && aligned16(y) && ((uintptr_t)idx % FullVec<T>::value) == 0;
+    DISPATCH_VEC(T, C, ok, maxpool_fwd_kernel, dim3((unsigned)(B * ly)), st, (const T*)x, (T*)y, idx, (int)B, (int)H,
+                 (int)W, Ho, Wo, (int)C, ly);
+    return 0;
+}
+template <typename T>
+static int do_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t B, int64_t H, int64_t W, int64_t C,
+                          hipStream_t st) {
+    const int Ho = (int)((H + 2 - 3) / 2 + 1), Wo = (int)((W + 2 - 3) / 2 + 1);
+    const int ly = lines_per_image(B, H);
+    const bool ok = aligned16(dy) && aligned16(dx) && ((uintptr_t)idx % FullVec<T>::value) == 0;
+    DISPATCH_VEC(T, C, ok, maxpool_bwd_kernel, dim3((unsigned)(B * ly)), st, (const T*)dy, idx, (T*)dx, (int)B, (int)H,
+                 (int)W, Ho, Wo, (int)C, ly);
+    return 0;
+}
+
+}  // namespace mrfp
+
+using namespace mrfp;
+
+extern "C" {
+
+int mrfp_bilinear_fwd(const void* x, const void* addend, void* y, int dtype, int64_t B, int64_t Hi, int64_t Wi,
+                      int64_t Ho, int64_t Wo, int64_t C, int64_t ld_in, void* stream) {
+    MRFP_CHECK(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && ld_in >= C, "bilinear_fwd: bad arguments");
+    if (dtype == MRFP_F32) return do_bilinear_fwd<float>(x, addend, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
+    if (dtype == MRFP_BF16) return do_bilinear_fwd<bf16>(x, addend, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
+    MRFP_CHECK(false, "bilinear_fwd: unknown dtype %d", dtype);
+}
+int mrfp_bilinear_bwd(const void* dy, void* dx, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
+                      int64_t C, int64_t ld_in, void* stream) {
+    MRFP_CHECK(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && ld_in >= C, "bilinear_bwd: bad arguments");
+    if (dtype == MRFP_F32) return do_bilinear_bwd<float>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
+    if (dtype == MRFP_BF16) return do_bilinear_bwd<bf16>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
+    MRFP_CHECK(false, "bilinear_bwd: unknown dtype %d", dtype);
+}
+int mrfp_maxpool_fwd(const void* x, void* y, uint8_t* idx, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
+                     void* stream) {
+    MRFP_CHECK(x && y && idx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_fwd: bad arguments");
+    if (dtype == MRFP_F32) return do_maxpool_fwd<float>(x, y, idx, B, H, W, C, (hipStream_t)stream);
+    if (dtype == MRFP_BF16) return do_maxpool_fwd<bf16>(x, y, idx, B, H, W, C, (hipStream_t)stream);
+    MRFP_CHECK(false, "maxpool_fwd: unknown dtype %d", dtype);
+}
+int mrfp_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int64_t B, int64_t H, int64_t W,
+                     int64_t C, void* stream) {
+    MRFP_CHECK(dy && dx && idx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd: bad arguments");
+    if (dtype == MRFP_F32) return do_maxpool_bwd<float>(dy, idx, dx, B, H, W, C, (hipStream_t)stream);
+    if (dtype == MRFP_BF16) return do_maxpool_bwd<bf16>(dy, idx, dx, B, H, W, C, (hipStream_t)stream);
+    MRFP_CHECK(false, "maxpool_bwd: unknown dtype %d", dtype);
+}
+
+}  // extern "C"

@@ -1,0 +1,493 @@
+// stats.hip -- per-channel statistics over NHWC rows and the per-op "finalize" kernels that
+// turn them into apply coefficients.  HBM-bound: every activation element is read exactly once
+// with 16-byte loads; partial sums go to a small fp32 workspace, are combined in fp64.
+//
+// Replaces (reference): F.batch_norm statistics behind Norm2d (mynn.py:19-25), InstanceNorm2d
+// (Resnet.py:176-178, 534-536), feat.mean((2,3)) / torch.std of NP+ (deepv3.py:268-277),
+// AdaptiveAvgPool2d(1) (deepv3.py:109).
+#include "common.hpp"
+
+namespace mrfp {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 1: partial sums.  grid.x = B * ly; block (b, j) walks lines oh = j, j+ly, ... of image b.
+// MODE 0: s += x, q += x*x                         (forward statistics)
+// MODE 1: s += dy', q += dy'*(x - mean[g,c])       (backward statistics; dy' masked by y > 0)
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int MODE>
+__global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ y, const float* __restrict__ mean,
+                                                         int per_image, RowGeom g, int ly, float* __restrict__ ws) {
+    __shared__ float sm[kThreads * 2 * VEC];
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(g.C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    const bool active = trow < L.rowthreads;
+    float* out = ws + (size_t)blockIdx.x * 2 * g.C;
+
+    for (int cv0 = 0; cv0 < L.lpr; cv0 += kThreads) {
+        const int cv = cv0 + tcol;
+        const bool on = active && cv < L.lpr;
+        float s[VEC], q[VEC], mu[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; mu[i] = 0.f; }
+        if (MODE == 1 && mean != nullptr && on) {
+            const float* mp = mean + (size_t)(per_image ? b : 0) * g.C + (size_t)cv * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) mu[i] = mp[i];
+        }
+        if (on) {
+            for (int oh = j; oh < g.Ho; oh += ly) {
+                const int ih = g.tabH ? g.tabH[oh] : oh;
+                const T* xl = x + ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
+                const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
+                for (int ow = trow; ow < g.Wo; ow += L.rowthreads) {
+                    const int iw = g.tabW ? g.tabW[ow] : ow;
+                    float xv[VEC];
+                    load_f<T, VEC>(xl + (size_t)iw * g.C, xv);
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) { s[i] += xv[i]; q[i] += xv[i] * xv[i]; }
+                    } else {
+                        float dv[VEC];
+                        load_f<T, VEC>(dy + dl + (size_t)ow * g.C, dv);
+                        if (y != nullptr) {
+                            float yv[VEC];
+                            load_f<T, VEC>(y + dl + (size_t)ow * g.C, yv);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) dv[i] = yv[i] > 0.f ? dv[i] : 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) { s[i] += dv[i]; q[i] += dv[i] * (xv[i] - mu[i]); }
+                    }
+                }
+            }
+        }
+        // combine the row-threads of each channel vector through LDS
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sm[(t * 2 + 0) * VEC + i] = s[i];
+            sm[(t * 2 + 1) * VEC + i] = q[i];
+        }
+        __syncthreads();
+        const int nout = L.colthreads * 2 * VEC;   // (tcol, stat, i)
+        for (int o = t; o < nout; o += kThreads) {
+            const int oc = o / (2 * VEC), rest = o % (2 * VEC);
+            if (cv0 + oc < L.lpr) {
+                float acc = 0.f;
+                for (int r = 0; r < L.rowthreads; ++r) acc += sm[((r * L.colthreads + oc) * 2) * VEC + rest];
+                const int stat = rest / VEC, i = rest % VEC;
+                out[(size_t)stat * g.C + (size_t)(cv0 + oc) * VEC + i] = acc;
+            }
+        }
+    }
+}
+
+template <typename T, int MODE>
+static int launch_stats(const void* x, const void* dy, const void* y, const float* mean, int per_image,
+                        int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
+                        const int32_t* tabH, const int32_t* tabW, float* ws, hipStream_t st) {
+    RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, tabH, tabW};
+    const int ly = lines_per_image(B, Ho);
+    dim3 grid((unsigned)(B * ly));
+    const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(x) && (MODE == 0 || (aligned16(dy) && (y == nullptr || aligned16(y))));
+    if (vec_ok)
+        hipLaunchKernelGGL((stats_kernel<T, FullVec<T>::value, MODE>), grid, dim3(kThreads), 0, st, (const T*)x,
+                           (const T*)dy, (const T*)y, mean, per_image, g, ly, ws);
+    else
+        hipLaunchKernelGGL((stats_kernel<T, 1, MODE>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)dy,
+                           (const T*)y, mean, per_image, g, ly, ws);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 2: combine partials.  block = 32 channels x 8 partial lanes; every thread sums a strided
+// subset of the partials of its channel in fp64; lanes are combined through LDS.
+// ------------------------------------------------------------------------------------------
+struct Red { double s, q; };
+
+__device__ __forceinline__ Red reduce_partials(const float* ws, int64_t first, int64_t n, int64_t C, int c, bool valid,
+                                               double (*sm)[2][32]) {
+    const int ty = threadIdx.y, tx = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    if (valid) {
+        for (int64_t p = first + ty; p < first + n; p += 8) {
+            s += (double)ws[(p * 2 + 0) * C + c];
+            q += (double)ws[(p * 2 + 1) * C + c];
+        }
+    }
+    __syncthreads();
+    sm[ty][0][tx] = s;
+    sm[ty][1][tx] = q;
+    __syncthreads();
+    Red r{0.0, 0.0};
+    if (ty == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r.s += sm[k][0][tx]; r.q += sm[k][1][tx]; }
+    }
+    return r;
+}
+
+__global__ void bn_finalize_kernel(const float* ws, int64_t nparts, double count, int C, const float* weight,
+                                   const float* bias, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean, float* invstd, float* A, float* S) {
+    __shared__ double sm[8][2][32];
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    const bool valid = c < C;
+    Red r = reduce_partials(ws, 0, nparts, C, c, valid, sm);
+    if (threadIdx.y == 0 && valid) {
+        const double m = r.s / count;
+        double var = r.q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const float w = weight ? weight[c] : 1.f, bb = bias ? bias[c] : 0.f;
+        mean[c] = (float)m;
+        invstd[c] = (float)is;
+        const float a = (float)(w * is);
+        A[c] = a;
+        S[c] = (float)(bb - m * (double)a);
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+    }
+}
+
+__global__ void bn_eval_coef_kernel(int C, const float* weight, const float* bias, const float* rm, const float* rv,
+                                    float eps, float* A, float* S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.0f / sqrtf(rv[c] + eps);
+    const float a = (weight ? weight[c] : 1.f) * is;
+    A[c] = a;
+    S[c] = (bias ? bias[c] : 0.f) - rm[c] * a;
+}
+
+// dx = w*invstd*(dy' - m1 - xhat*m2): P = w*invstd, Q = -w*invstd^3*Sq/N, R = -P*Ss/N - Q*mean
+__device__ __forceinline__ void norm_bwd_coef(double Ss, double Sq, double count, float w, float mean, float invstd,
+                                              float& P, float& Q, float& R) {
+    const double is = invstd;
+    const double p = (double)w * is;
+    const double qq = -(double)w * is * is * is * Sq / count;
+    P = (float)p;
+    Q = (float)qq;
+    R = (float)(-p * Ss / count - qq * (double)mean);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* ws, int64_t nparts, double count, int C, const float* weight,
+                                       const float* mean, const float* invstd, float* dweight, float* dbias,
+                                       float* P, float* Q, float* R) {
+    __shared__ double sm[8][2][32];
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    const bool valid = c < C;
+    Red r = reduce_partials(ws, 0, nparts, C, c, valid, sm);
+    if (threadIdx.y == 0 && valid) {
+        if (dbias) dbias[c] = (float)r.s;
+        if (dweight) dweight[c] = (float)(r.q * (double)invstd[c]);
+        norm_bwd_coef(r.s, r.q, count, weight ? weight[c] : 1.f, mean[c], invstd[c], P[c], Q[c], R[c]);
+    }
+}
+
+// InstanceNorm: grid (C/32, B)
+__global__ void in_finalize_kernel(const float* ws, int64_t nslab, double count, int C, const float* weight,
+                                   const float* bias, float eps, float* mean, float* invstd, float* A, float* S) {
+    __shared__ double sm[8][2][32];
+    const int c = blockIdx.x * 32 + threadIdx.x, b = blockIdx.y;
+    const bool valid = c < C;
+    Red r = reduce_partials(ws, (int64_t)b * nslab, nslab, C, c, valid, sm);
+    if (threadIdx.y == 0 && valid) {
+        const double m = r.s / count;
+        double var = r.q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const size_t o = (size_t)b * C + c;
+        mean[o] = (float)m;
+        invstd[o] = (float)is;
+        const float a = (float)((weight ? weight[c] : 1.f) * is);
+        A[o] = a;
+        S[o] = (float)((bias ? bias[c] : 0.f) - m * (double)a);
+    }
+}
+
+// InstanceNorm backward: grid (C/32); loops over the images so that dweight/dbias are summed in a
+// fixed order (bitwise reproducible, no atomics).
+__global__ void in_bwd_finalize_kernel(const float* ws, int B, int64_t nslab, double count, int C, const float* weight,
+                                       const float* mean, const float* invstd, float* dweight, float* dbias,
+                                       float* P, float* Q, float* R) {
+    __shared__ double sm[8][2][32];
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    const bool valid = c < C;
+    double dw = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) {
+        Red r = reduce_partials(ws, (int64_t)b * nslab, nslab, C, c, valid, sm);
+        if (threadIdx.y == 0 && valid) {
+            const size_t o = (size_t)b * C + c;
+            db += r.s;
+            dw += r.q * (double)invstd[o];
+            norm_bwd_coef(r.s, r.q, count, weight ? weight[c] : 1.f, mean[o], invstd[o], P[o], Q[o], R[o]);
+        }
+    }
+    if (threadIdx.y == 0 && valid) {
+        if (dweight) dweight[c] = (float)dw;
+        if (dbias) dbias[c] = (float)db;
+    }
+}
+
+// plane sums -> fp32 [B][C] scaled by `scale` (mean: 1/count; raw sum: 1)
+__global__ void plane_sum_kernel(const float* ws, int64_t nslab, double scale, int C, float* out) {
+    __shared__ double sm[8][2][32];
+    const int c = blockIdx.x * 32 + threadIdx.x, b = blockIdx.y;
+    const bool valid = c < C;
+    Red r = reduce_partials(ws, (int64_t)b * nslab, nslab, C, c, valid, sm);
+    if (threadIdx.y == 0 && valid) out[(size_t)b * C + c] = (float)(r.s * scale);
+}
+
+template <typename T>
+__global__ void cast_out_kernel(const float* in, T* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = from_f<T>(in[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// NP+ coefficient kernels: one workgroup (the data is [B][C], a few KB)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max(float v, float* sm) {
+    const int t = threadIdx.x;
+    sm[t] = v;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (t < s) sm[t] = fmaxf(sm[t], sm[t + s]);
+        __syncthreads();
+    }
+    const float r = sm[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    const int t = threadIdx.x;
+    sm[t] = v;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (t < s) sm[t] += sm[t + s];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+// reference deepv3.py:269-276
+__global__ __launch_bounds__(kThreads) void np_coef_kernel(int B, int C, const float* alpha, const float* beta_noise,
+                                                           const float* mu, float* sigma, float* A, float* S) {
+    __shared__ float smf[kThreads];
+    float lmax = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+        double m = 0.0;
+        for (int b = 0; b < B; ++b) m += (double)mu[(size_t)b * C + c];
+        m /= B;
+        double v = 0.0;
+        for (int b = 0; b < B; ++b) { const double d = (double)mu[(size_t)b * C + c] - m; v += d * d; }
+        const float sg = (float)sqrt(v / (double)(B - 1));   // unbiased; B==1 -> NaN like torch.std
+        sigma[c] = sg;
+        lmax = fmaxf(lmax, sg);
+        if (sg != sg) lmax = sg;                              // propagate NaN
+    }
+    const float M = block_max(lmax, smf);
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+        const float scale = sigma[c] / M * 1.5f;
+        for (int b = 0; b < B; ++b) {
+            const size_t o = (size_t)b * C + c;
+            const float beta = 1.f + beta_noise[o] * scale;
+            A[o] = alpha[o];
+            S[o] = (beta - alpha[o]) * mu[o];
+        }
+    }
+}
+
+// Backward of the same expression.  G[b][c] = sum_hw dy.
+//   dL/dbeta[b,c] = mu*G ; ds[c] = sum_b dL/dbeta*noise ; s = 1.5*sigma/M (M = sigma[c*])
+//   dL/dsigma[c] = 1.5*ds[c]/M - [c==c*] * sum_c' 1.5*ds[c']*sigma[c']/M^2
+//   dL/dmu[b,c]  = (beta-alpha)*G + dL/dsigma[c]*(mu-mbar)/((B-1)*sigma[c])
+//   dx = alpha*dy + K,  K = dL/dmu / HW
+__global__ __launch_bounds__(kThreads) void np_bwd_coef_kernel(int B, int C, double hw, const float* alpha,
+                                                               const float* beta_noise, const float* mu,
+                                                               const float* sigma, const float* G, float* K) {
+    __shared__ float smf[kThreads];
+    __shared__ double smd[kThreads];
+    float lmax = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += kThreads) lmax = fmaxf(lmax, sigma[c]);
+    const float M = block_max(lmax, smf);
+    // first channel attaining the maximum (torch.max() sends the gradient to one arg-max)
+    int larg = 0x7fffffff;
+    for (int c = threadIdx.x; c < C; c += kThreads)
+        if (sigma[c] == M && c < larg) larg = c;
+    const int cstar = -(int)block_max(-(float)larg, smf);
+    double lt = 0.0;
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+        double ds = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const size_t o = (size_t)b * C + c;
+            ds += (double)mu[o] * (double)G[o] * (double)beta_noise[o];
+        }
+        lt += ds * (double)sigma[c];
+    }
+    const double T = block_sum(lt, smd);
+    const double Md = (double)M;
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+        double ds = 0.0, mbar = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const size_t o = (size_t)b * C + c;
+            ds += (double)mu[o] * (double)G[o] * (double)beta_noise[o];
+            mbar += (double)mu[o];
+        }
+        mbar /= B;
+        double dsig = 1.5 * ds / Md;
+        if (c == cstar) dsig -= 1.5 * T / (Md * Md);
+        const double scale = (double)sigma[c] / Md * 1.5;
+        for (int b = 0; b < B; ++b) {
+            const size_t o = (size_t)b * C + c;
+            const double beta = 1.0 + (double)beta_noise[o] * scale;
+            double dmu = (beta - (double)alpha[o]) * (double)G[o];
+            dmu += dsig * ((double)mu[o] - mbar) / ((double)(B - 1) * (double)sigma[c]);
+            K[o] = (float)(dmu / hw);
+        }
+    }
+}
+
+}  // namespace mrfp
+
+using namespace mrfp;
+
+extern "C" {
+
+int mrfp_version(void) { return 100; }
+const char* mrfp_last_error(void) { return mrfp::g_err; }
+
+int64_t mrfp_stats_nslab(int64_t B, int64_t Ho) { return lines_per_image(B, Ho); }
+
+int mrfp_stats_fwd(const void* x, int dtype, int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
+                   const int32_t* tabH, const int32_t* tabW, float* ws, void* stream) {
+    MRFP_CHECK(x && ws && B > 0 && Ho > 0 && Wo > 0 && C > 0, "stats_fwd: bad arguments");
+    MRFP_CHECK(C <= 65536 && B * Ho < (1LL << 31), "stats_fwd: shape out of range");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return launch_stats<float, 0>(x, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_BF16) return launch_stats<bf16, 0>(x, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    MRFP_CHECK(false, "stats_fwd: unknown dtype %d", dtype);
+}
+
+int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* mean, int per_image, int dtype,
+                   int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws, const int32_t* tabH,
+                   const int32_t* tabW, float* ws, void* stream) {
+    MRFP_CHECK(dy && x && ws && B > 0 && Ho > 0 && Wo > 0 && C > 0, "stats_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return launch_stats<float, 1>(x, dy, y, mean, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_BF16) return launch_stats<bf16, 1>(x, dy, y, mean, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    MRFP_CHECK(false, "stats_bwd: unknown dtype %d", dtype);
+}
+
+int mrfp_bn_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* weight,
+                     const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                     float* mean, float* invstd, float* A, float* S, void* stream) {
+    MRFP_CHECK(ws && mean && invstd && A && S && C > 0 && count > 0, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, ws,
+                       B * nslab, (double)count, (int)C, weight, bias, eps, momentum, running_mean, running_var, mean,
+                       invstd, A, S);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_bn_eval_coef(int64_t C, const float* weight, const float* bias, const float* running_mean,
+                      const float* running_var, float eps, float* A, float* S, void* stream) {
+    MRFP_CHECK(running_mean && running_var && A && S && C > 0, "bn_eval_coef: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)C,
+                       weight, bias, running_mean, running_var, eps, A, S);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_bn_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* weight,
+                         const float* mean, const float* invstd, float* dweight, float* dbias, float* P, float* Q,
+                         float* R, void* stream) {
+    MRFP_CHECK(ws && mean && invstd && P && Q && R && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, ws,
+                       B * nslab, (double)count, (int)C, weight, mean, invstd, dweight, dbias, P, Q, R);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_in_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* weight,
+                     const float* bias, float eps, float* mean, float* invstd, float* A, float* S, void* stream) {
+    MRFP_CHECK(ws && mean && invstd && A && S && C > 0 && count > 0 && B > 0 && B < 65536, "in_finalize: bad arguments");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0,
+                       (hipStream_t)stream, ws, nslab, (double)count, (int)C, weight, bias, eps, mean, invstd, A, S);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_in_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* weight,
+                         const float* mean, const float* invstd, float* dweight, float* dbias, float* P, float* Q,
+                         float* R, void* stream) {
+    MRFP_CHECK(ws && mean && invstd && P && Q && R && C > 0 && count > 0, "in_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, ws,
+                       (int)B, nslab, (double)count, (int)C, weight, mean, invstd, dweight, dbias, P, Q, R);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_np_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* alpha,
+                     const float* beta_noise, float* mu, float* sigma, float* A, float* S, void* stream) {
+    MRFP_CHECK(ws && alpha && beta_noise && mu && sigma && A && S && C > 0 && B > 0 && B < 65536, "np_finalize: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, st, ws, nslab,
+                       1.0 / (double)count, (int)C, mu);
+    MRFP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(np_coef_kernel, dim3(1), dim3(kThreads), 0, st, (int)B, (int)C, alpha, beta_noise, mu, sigma, A, S);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_np_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* alpha,
+                         const float* beta_noise, const float* mu, const float* sigma, float* Gtmp, float* K,
+                         void* stream) {
+    MRFP_CHECK(ws && alpha && beta_noise && mu && sigma && Gtmp && K && C > 0 && B > 0 && B < 65536, "np_bwd_finalize: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, st, ws, nslab, 1.0,
+                       (int)C, Gtmp);
+    MRFP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(np_bwd_coef_kernel, dim3(1), dim3(kThreads), 0, st, (int)B, (int)C, (double)count, alpha,
+                       beta_noise, mu, sigma, Gtmp, K);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_mean_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, float* tmp, void* out,
+                       int dtype, void* stream) {
+    MRFP_CHECK(ws && out && tmp && C > 0 && B > 0 && B < 65536, "mean_finalize: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* dst = dtype == MRFP_F32 ? (float*)out : tmp;
+    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, st, ws, nslab,
+                       1.0 / (double)count, (int)C, dst);
+    MRFP_LAUNCH_CHECK();
+    if (dtype == MRFP_BF16) {
+        const int64_t n = B * C;
+        hipLaunchKernelGGL((cast_out_kernel<bf16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, (bf16*)out, n);
+        MRFP_LAUNCH_CHECK();
+    } else {
+        MRFP_CHECK(dtype == MRFP_F32, "mean_finalize: unknown dtype %d", dtype);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""Train-step and eval harness: the semantics of the reference's driver loops (reference
+main.py:822-839 optimiser + poly LR, 857-864 train step, 887-913 eval loop) re-designed for one
+process per MI355X:
+
+  * all trainable parameters, their gradients and the momentum live in three flat fp32 arenas
+    (parameters keep their names / shapes / state_dict ABI as views), so the optimiser is ONE fused
+    HIP kernel and the data-parallel exchange works on contiguous buckets without packing copies;
+  * gradient buckets (contiguous arena ranges, filled in reverse forward order) are all-reduced by
+    RCCL over xGMI on a side HIP stream as soon as autograd has finished the last tensor of a bucket,
+    overlapping the exchange with the rest of backward; no other collective exists on the data path;
+  * BatchNorm / NP+ statistics stay per replica: with 16 images per GPU that is exactly the
+    statistical population the reference's single-GPU run sees.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def poly_lr_factor(it: int, max_iter: int = 40000, power: float = 0.9) -> float:
+    """reference main.py:832-839 (LRPolicy)."""
+    return math.pow(1 - it / max_iter, power)
+
+
+class FlatSGD:
+    """torch.optim.SGD(lr, momentum=0.9, weight_decay=5e-4) + LambdaLR(poly 0.9) over flat arenas."""
+
+    def __init__(self, model: torch.nn.Module, lr=1e-2, momentum=0.9, weight_decay=5e-4, max_iter=40000, power=0.9):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise _lib.MrfpHipError("FlatSGD needs the model on the GPU: the HIP path has no CPU fallback")
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned inside the arena
+        self.n = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+            p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.base_lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.max_iter, self.power = max_iter, power
+        self.it = 0
+
+    @property
+    def lr(self):
+        return self.base_lr * poly_lr_factor(self.it, self.max_iter, self.power)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):   # autograd may have replaced .grad (first backward)
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def step(self, gscale: float = 1.0):
+        call("mrfp_sgd_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), self.n, float(self.lr),
+             float(self.momentum), float(self.weight_decay), float(gscale), int(self.it == 0), stream())
+        # the fused kernel wrote the arena behind autograd's version counters: invalidate the derived
+        # weight packs explicitly (mrfp_amd/conv.py rebuilds them on next use)
+        from . import conv
+        conv.invalidate_packs()
+        self.it += 1                                  # scheduler.step()
+
+
+class GradSync:
+    """Bucketed RCCL all-reduce of the flat gradient arena, overlapped with backward."""
+
+    def __init__(self, opt: FlatSGD, bucket_mb: float = 32.0, group=None):
+        self.opt, self.group = opt, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1
+        self.buckets: List[tuple] = []
+        if not self.enabled:
+            return
+        cap = int(bucket_mb * (1 << 20) / 4)
+        # buckets are contiguous arena ranges, cut from the END (gradients arrive in reverse forward order)
+        end = opt.n
+        members: List[int] = []
+        self.bucket_of = [0] * len(opt.params)
+        for i in range(len(opt.params) - 1, -1, -1):
+            members.append(i)
+            if end - opt.offsets[i] >= cap or i == 0:
+                self.buckets.append((opt.offsets[i], end, list(members)))
+                end, members = opt.offsets[i], []
+        for b, (_, _, mem) in enumerate(self.buckets):
+            for i in mem:
+                self.bucket_of[i] = b
+        self.pending = [0] * len(self.buckets)
+        self.works = []
+        self.side = torch.cuda.Stream()
+        for i, p in enumerate(opt.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.works.append(dist.all_reduce(self.opt.flat_g[lo:hi], group=self.group, async_op=True))
+
+    def begin(self):
+        if self.enabled:
+            self.pending = [len(m) for _, _, m in self.buckets]
+            self.works = []
+
+    def finish(self):
+        """Blocks the compute stream until every bucket has been reduced; returns the 1/world scale."""
+        if not self.enabled:
+            return 1.0
+        for b, n in enumerate(self.pending):        # buckets whose tensors got no gradient this step
+            if n > 0:
+                self.pending[b] = 0
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        torch.cuda.current_stream().wait_stream(self.side)
+        return 1.0 / self.world
+
+
+class Trainer:
+    """zero_grad -> forward -> backward (+ overlapped all-reduce) -> fused SGD step -> LR step."""
+
+    def __init__(self, model, lr=1e-2, momentum=0.9, weight_decay=5e-4, max_iter=40000, bucket_mb=32.0):
+        self.model = model
+        self.opt = FlatSGD(model, lr, momentum, weight_decay, max_iter)
+        self.sync = GradSync(self.opt, bucket_mb)
+
+    def step(self, img, label):
+        self.opt.zero_grad()
+        self.sync.begin()
+        loss = self.model(img, label, training=True)
+        loss.backward()
+        gscale = self.sync.finish()
+        self.opt.step(gscale)
+        return loss
+
+
+@torch.no_grad()
+def evaluate(model, batches, num_classes=19):
+    """reference main.py:887-913: model.eval(), per-image arg-max + confusion histogram (on the device,
+    one 19x19 int64 D2H at the end instead of two full-logit copies per image), mIoU as metrics.py:60-85."""
+    from . import metrics, ops
+    model.eval()
+    hist, dropped = None, 0
+    for img, label in batches:
+        if img.shape[2:] != label.shape[1:]:        # reference main.py:894, 910-912
+            dropped += 1
+            continue
+        logits = model(img, training=False)
+        hist, _ = ops.argmax_hist(logits, label, hist)
+    if hist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(hist)
+    h = hist.cpu().numpy() if hist is not None else None
+    return h, (metrics.miou_from_hist(h) if h is not None else 0.0), dropped

@@ -1,0 +1,522 @@
+"""Host-side operator layer: torch.autograd.Functions over the C ABI of libmrfp_hip.so.
+
+Activations are torch tensors of logical shape [B,C,H,W] in channels_last memory format, i.e.
+physically NHWC -- the layout every kernel in mrfp_amd/csrc assumes.  PyTorch is used here for
+device memory (caching allocator), streams and the autograd tape only; every arithmetic op on
+an activation goes through a hand-written HIP kernel, and a missing library raises
+(mrfp_amd/_lib.py) -- there is no eager / CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from functools import lru_cache
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, dt, ptr, stream
+
+CL = torch.channels_last
+
+
+# ------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------
+def to_cl(x: torch.Tensor) -> torch.Tensor:
+    """Dense NHWC storage for a logical NCHW tensor (no copy if already so)."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D activation, got %s" % (tuple(x.shape),))
+    return x.contiguous(memory_format=CL)
+
+
+def empty_cl(B, C, H, W, dtype, device) -> torch.Tensor:
+    return torch.empty((B, C, H, W), dtype=dtype, device=device, memory_format=CL)
+
+
+def zeros_cl(B, C, H, W, dtype, device) -> torch.Tensor:
+    return torch.zeros((B, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def _chk(x: torch.Tensor, name="x") -> torch.Tensor:
+    if not x.is_cuda:
+        raise _lib.MrfpHipError("%s must live on the GPU (got %s): the HIP path has no CPU fallback" % (name, x.device))
+    if x.dim() != 4 or not x.is_contiguous(memory_format=CL):
+        x = to_cl(x)
+    return x
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.detach().float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+# nearest-neighbour resize plans (HRFP, reference deepv3.py:320-327)
+# ------------------------------------------------------------------------------------------
+def nearest_out_size(in_size: int, scale: float) -> int:
+    """ATen: floor(in * scale_factor) in double."""
+    return int(math.floor(float(in_size) * scale))
+
+
+def _nearest_table(in_size: int, out_size: int, scale: Optional[float]) -> np.ndarray:
+    """ATen nearest rule in float32: src = min(floor(dst * s), in-1), s = 1/scale_factor if a scale
+    factor was given else in/out."""
+    s = np.float32(1.0 / scale) if scale is not None else np.float32(in_size) / np.float32(out_size)
+    src = np.floor(np.arange(out_size, dtype=np.float32) * s).astype(np.int64)
+    return np.minimum(src, in_size - 1).astype(np.int32)
+
+
+def _inverse_table(tab: np.ndarray, in_size: int) -> np.ndarray:
+    """[2*in]: half-open destination range reading each source index (tab is non-decreasing)."""
+    lo = np.searchsorted(tab, np.arange(in_size), side="left")
+    hi = np.searchsorted(tab, np.arange(in_size), side="right")
+    return np.stack([lo, hi], 1).astype(np.int32).reshape(-1)
+
+
+class NearestPlan:
+    """Index tables of one F.interpolate(mode='nearest') call, resident on the device."""
+
+    def __init__(self, Hs, Ws, Ho, Wo, scale, device):
+        self.Hs, self.Ws, self.Ho, self.Wo = Hs, Ws, Ho, Wo
+        th, tw = _nearest_table(Hs, Ho, scale), _nearest_table(Ws, Wo, scale)
+        self.tabH = torch.from_numpy(th).to(device)
+        self.tabW = torch.from_numpy(tw).to(device)
+        self.invH = torch.from_numpy(_inverse_table(th, Hs)).to(device)
+        self.invW = torch.from_numpy(_inverse_table(tw, Ws)).to(device)
+
+
+@lru_cache(maxsize=256)
+def _plan_cached(Hs, Ws, Ho, Wo, scale, device_str):
+    return NearestPlan(Hs, Ws, Ho, Wo, scale, torch.device(device_str))
+
+
+def nearest_plan(Hs: int, Ws: int, *, scale: Optional[float] = None, size: Optional[Tuple[int, int]] = None,
+                 device="cuda") -> NearestPlan:
+    if scale is not None:
+        Ho, Wo = nearest_out_size(Hs, scale), nearest_out_size(Ws, scale)
+    else:
+        Ho, Wo = int(size[0]), int(size[1])
+    return _plan_cached(Hs, Ws, Ho, Wo, scale, str(device))
+
+
+# ------------------------------------------------------------------------------------------
+# statistics plumbing
+# ------------------------------------------------------------------------------------------
+def _geom(x, plan: Optional[NearestPlan]):
+    B, C, Hs, Ws = x.shape
+    if plan is None:
+        return B, Hs, Ws, C, Hs, Ws, None, None, None, None
+    if (plan.Hs, plan.Ws) != (Hs, Ws):
+        raise _lib.MrfpHipError("resize plan %dx%d does not match input %dx%d" % (plan.Hs, plan.Ws, Hs, Ws))
+    return B, plan.Ho, plan.Wo, C, Hs, Ws, plan.tabH, plan.tabW, plan.invH, plan.invW
+
+
+def _stats_ws(B, Ho, C, device):
+    nslab = int(_lib.lib().mrfp_stats_nslab(B, Ho))
+    return nslab, torch.empty(B * nslab * 2 * C, dtype=torch.float32, device=device)
+
+
+def _stats_fwd(x, plan):
+    B, Ho, Wo, C, Hs, Ws, tH, tW, _, _ = _geom(x, plan)
+    nslab, ws = _stats_ws(B, Ho, C, x.device)
+    call("mrfp_stats_fwd", ptr(x), dt(x), B, Ho, Wo, C, Hs, Ws, ptr(tH), ptr(tW), ptr(ws), stream())
+    return nslab, ws
+
+
+def _stats_bwd(dy, x, y, mean, per_image, plan):
+    B, Ho, Wo, C, Hs, Ws, tH, tW, _, _ = _geom(x, plan)
+    nslab, ws = _stats_ws(B, Ho, C, x.device)
+    call("mrfp_stats_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), int(per_image), dt(x), B, Ho, Wo, C, Hs, Ws,
+         ptr(tH), ptr(tW), ptr(ws), stream())
+    return nslab, ws
+
+
+def _affine_fwd(x, res, A, S, per_image, relu, plan, like=None):
+    src = x if x is not None else like
+    B, Ho, Wo, C, Hs, Ws, tH, tW, _, _ = _geom(src, plan)
+    y = empty_cl(B, C, Ho, Wo, src.dtype, src.device)
+    call("mrfp_affine_fwd", ptr(x), ptr(res), ptr(y), dt(src), B, Ho, Wo, C, Hs, Ws, ptr(tH), ptr(tW),
+         ptr(A), ptr(S), int(per_image), int(relu), stream())
+    return y
+
+
+def _affine_bwd(dy, x, y, P, Q, R, per_image, plan, want_dres, like):
+    B, Ho, Wo, C, Hs, Ws, _, _, iH, iW = _geom(like, plan)
+    dx = empty_cl(B, C, Hs, Ws, dy.dtype, dy.device)
+    dres = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device) if want_dres else None
+    call("mrfp_affine_bwd", ptr(dy), ptr(x), ptr(y), ptr(dx), ptr(dres), dt(dy), B, Ho, Wo, C, Hs, Ws,
+         ptr(iH), ptr(iW), ptr(P), ptr(Q), ptr(R), int(per_image), stream())
+    return dx, dres
+
+
+# ------------------------------------------------------------------------------------------
+# BatchNorm (+ nearest resize in front) (+ residual) (+ ReLU)
+# ------------------------------------------------------------------------------------------
+class _BatchNormAct(torch.autograd.Function):
+    """y = act(BN(resize(x)) + res).  reference: Norm2d/SyncBatchNorm on one process = F.batch_norm
+    (mynn.py:19-25), Bottleneck tail (Resnet.py:202-225), HRFP stage (deepv3.py:320-327)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, training, momentum, eps, relu, plan):
+        x = _chk(x)
+        res = _chk(res, "res") if res is not None else None
+        B, Ho, Wo, C, Hs, Ws, *_ = _geom(x, plan)
+        dev = x.device
+        w32, b32 = _f32(weight), _f32(bias)
+        coef = torch.empty(4 * C, dtype=torch.float32, device=dev)
+        mean, invstd, A, S = coef[0:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:4 * C]
+        if training:
+            nslab, ws = _stats_fwd(x, plan)
+            call("mrfp_bn_finalize", ptr(ws), B, nslab, B * Ho * Wo, C, ptr(w32), ptr(b32), float(eps),
+                 float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(A), ptr(S), stream())
+        else:
+            call("mrfp_bn_eval_coef", C, ptr(w32), ptr(b32), ptr(running_mean), ptr(running_var), float(eps),
+                 ptr(A), ptr(S), stream())
+        y = _affine_fwd(x, res, A, S, False, relu, plan)
+        ctx.plan, ctx.relu, ctx.training, ctx.has_res = plan, relu, training, res is not None
+        ctx.save_for_backward(x, y if relu else None, w32, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w32, mean, invstd = ctx.saved_tensors
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not on the MRFP hot path")
+        dy = _chk(dy, "dy")
+        plan = ctx.plan
+        B, Ho, Wo, C, *_ = _geom(x, plan)
+        nslab, ws = _stats_bwd(dy, x, y, mean, False, plan)
+        out = torch.empty(5 * C, dtype=torch.float32, device=dy.device)
+        dw, db, P, Q, R = (out[i * C:(i + 1) * C] for i in range(5))
+        call("mrfp_bn_bwd_finalize", ptr(ws), B, nslab, B * Ho * Wo, C, ptr(w32), ptr(mean), ptr(invstd),
+             ptr(dw), ptr(db), ptr(P), ptr(Q), ptr(R), stream())
+        dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x)
+        return dx, dw, db, None, None, dres, None, None, None, None, None
+
+
+def batch_norm_act(x, weight, bias, running_mean, running_var, *, training, momentum=0.1, eps=1e-5,
+                   relu=False, res=None, plan=None):
+    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, res, training, momentum, eps, relu, plan)
+
+
+# ------------------------------------------------------------------------------------------
+# InstanceNorm (+ReLU)
+# ------------------------------------------------------------------------------------------
+class _InstanceNormAct(torch.autograd.Function):
+    """nn.InstanceNorm2d(affine) (+ReLU): reference Resnet.py:176-178, 218-225, 534-536."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        x = _chk(x)
+        B, C, H, W = x.shape
+        w32, b32 = _f32(weight), _f32(bias)
+        coef = torch.empty(4 * B * C, dtype=torch.float32, device=x.device)
+        n = B * C
+        mean, invstd, A, S = coef[0:n], coef[n:2 * n], coef[2 * n:3 * n], coef[3 * n:4 * n]
+        nslab, ws = _stats_fwd(x, None)
+        call("mrfp_in_finalize", ptr(ws), B, nslab, H * W, C, ptr(w32), ptr(b32), float(eps), ptr(mean),
+             ptr(invstd), ptr(A), ptr(S), stream())
+        y = _affine_fwd(x, None, A, S, True, relu, None)
+        ctx.relu, ctx.affine = relu, weight is not None
+        ctx.save_for_backward(x, y if relu else None, w32, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w32, mean, invstd = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        B, C, H, W = x.shape
+        nslab, ws = _stats_bwd(dy, x, y, mean, True, None)
+        pqr = torch.empty(3 * B * C, dtype=torch.float32, device=dy.device)
+        n = B * C
+        P, Q, R = pqr[0:n], pqr[n:2 * n], pqr[2 * n:3 * n]
+        dwb = torch.empty(2 * C, dtype=torch.float32, device=dy.device)
+        call("mrfp_in_bwd_finalize", ptr(ws), B, nslab, H * W, C, ptr(w32), ptr(mean), ptr(invstd),
+             ptr(dwb[:C]), ptr(dwb[C:]), ptr(P), ptr(Q), ptr(R), stream())
+        dx, _ = _affine_bwd(dy, x, y, P, Q, R, True, None, False, x)
+        if ctx.affine:
+            return dx, dwb[:C], dwb[C:], None, None
+        return dx, None, None, None, None
+
+
+def instance_norm_act(x, weight, bias, *, eps=1e-5, relu=False):
+    return _InstanceNormAct.apply(x, weight, bias, eps, relu)
+
+
+# ------------------------------------------------------------------------------------------
+# NP+
+# ------------------------------------------------------------------------------------------
+class _NPPlus(torch.autograd.Function):
+    """Normalization_Perturbation_Plus, reference deepv3.py:268-277; alpha / beta_noise are the two
+    normal draws ([B,C,1,1])."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta_noise):
+        x = _chk(x)
+        B, C, H, W = x.shape
+        a32 = alpha.detach().float().reshape(B, C).contiguous()
+        n32 = beta_noise.detach().float().reshape(B, C).contiguous()
+        buf = torch.empty(3 * B * C + C, dtype=torch.float32, device=x.device)
+        n = B * C
+        mu, A, S, sigma = buf[0:n], buf[n:2 * n], buf[2 * n:3 * n], buf[3 * n:3 * n + C]
+        nslab, ws = _stats_fwd(x, None)
+        call("mrfp_np_finalize", ptr(ws), B, nslab, H * W, C, ptr(a32), ptr(n32), ptr(mu), ptr(sigma), ptr(A),
+             ptr(S), stream())
+        y = _affine_fwd(x, None, A, S, True, False, None)
+        ctx.save_for_backward(a32, n32, mu, sigma)
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a32, n32, mu, sigma = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        B, C, H, W = ctx.shape
+        nslab, ws = _stats_bwd(dy, dy, None, None, True, None)       # G[b,c] = sum_hw dy
+        tmp = torch.empty(2 * B * C, dtype=torch.float32, device=dy.device)
+        G, K = tmp[:B * C], tmp[B * C:]
+        call("mrfp_np_bwd_finalize", ptr(ws), B, nslab, H * W, C, ptr(a32), ptr(n32), ptr(mu), ptr(sigma),
+             ptr(G), ptr(K), stream())
+        dx = empty_cl(B, C, H, W, dy.dtype, dy.device)               # dx = alpha*dy + K
+        call("mrfp_affine_fwd", ptr(dy), None, ptr(dx), dt(dy), B, H, W, C, H, W, None, None, ptr(a32), ptr(K), 1, 0,
+             stream())
+        return dx, None, None
+
+
+def np_plus(x, alpha, beta_noise):
+    return _NPPlus.apply(x, alpha, beta_noise)
+
+
+# ------------------------------------------------------------------------------------------
+# bilinear align_corners resize (+ add)
+# ------------------------------------------------------------------------------------------
+class _Bilinear(torch.autograd.Function):
+    """Upsample(): reference mynn.py:114-119; with addend: torch.add(OCout_dec, Upsample(dec1)) of
+    deepv3.py:356-357 fused into one pass."""
+
+    @staticmethod
+    def forward(ctx, x, addend, Ho, Wo, channels):
+        x = _chk(x)
+        addend = _chk(addend, "addend") if addend is not None else None
+        B, ld, Hi, Wi = x.shape
+        C = ld if channels is None else int(channels)
+        y = empty_cl(B, C, Ho, Wo, x.dtype, x.device)
+        call("mrfp_bilinear_fwd", ptr(x), ptr(addend), ptr(y), dt(x), B, Hi, Wi, Ho, Wo, C, ld, stream())
+        ctx.dims = (B, C, ld, Hi, Wi, Ho, Wo)
+        ctx.has_add = addend is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        B, C, ld, Hi, Wi, Ho, Wo = ctx.dims
+        if ld == C:
+            dx = empty_cl(B, ld, Hi, Wi, dy.dtype, dy.device)
+        else:       # pad channels of the low-resolution gradient stay zero
+            dx = zeros_cl(B, ld, Hi, Wi, dy.dtype, dy.device)
+        call("mrfp_bilinear_bwd", ptr(dy), ptr(dx), dt(dy), B, Hi, Wi, Ho, Wo, C, ld, stream())
+        return dx, (dy if ctx.has_add else None), None, None, None
+
+
+def upsample_bilinear(x, size, addend=None, channels=None):
+    """channels: use only the first `channels` channels of x (x is a channel-padded buffer)."""
+    return _Bilinear.apply(x, addend, int(size[0]), int(size[1]), channels)
+
+
+# ------------------------------------------------------------------------------------------
+# max pool 3x3 / stride 2 / pad 1
+# ------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1): reference Resnet.py:551, deepv3.py:315."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = empty_cl(B, C, Ho, Wo, x.dtype, x.device)
+        idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+        call("mrfp_maxpool_fwd", ptr(x), ptr(y), ptr(idx), dt(x), B, H, W, C, stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        B, C, H, W = ctx.dims
+        dx = empty_cl(B, C, H, W, dy.dtype, dy.device)
+        call("mrfp_maxpool_bwd", ptr(dy), ptr(idx), ptr(dx), dt(dy), B, H, W, C, stream())
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPool.apply(x)
+
+
+# ------------------------------------------------------------------------------------------
+# global average pool
+# ------------------------------------------------------------------------------------------
+class _GlobalAvgPool(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1): reference deepv3.py:109, 117."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        B, C, H, W = x.shape
+        nslab, ws = _stats_fwd(x, None)
+        out = empty_cl(B, C, 1, 1, x.dtype, x.device)
+        tmp = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        call("mrfp_mean_finalize", ptr(ws), B, nslab, H * W, C, ptr(tmp), ptr(out), dt(x), stream())
+        ctx.dims = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.dims
+        S = (g.detach().float().reshape(B, C) / float(H * W)).contiguous()
+        dx = empty_cl(B, C, H, W, g.dtype, g.device)
+        call("mrfp_affine_fwd", None, None, ptr(dx), dt(g), B, H, W, C, H, W, None, None, None, ptr(S), 1, 0, stream())
+        return dx
+
+
+def global_avg_pool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+# ------------------------------------------------------------------------------------------
+# elementwise add
+# ------------------------------------------------------------------------------------------
+class _Add(torch.autograd.Function):
+    """torch.add(OCout, x): reference deepv3.py:330."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "a"), _chk(b, "b")
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise _lib.MrfpHipError("add: shape/dtype mismatch %s %s" % (tuple(a.shape), tuple(b.shape)))
+        y = torch.empty_like(a, memory_format=CL)
+        call("mrfp_add", ptr(a), ptr(b), ptr(y), dt(a), a.numel(), stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------
+# cross entropy (ignore_index) -- scalar fp32 loss
+# ------------------------------------------------------------------------------------------
+class _CrossEntropy(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index=255): reference main.py:822, deepv3.py:363."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits = _chk(logits, "logits")
+        B, C, H, W = logits.shape
+        target = target.contiguous()
+        if target.dtype != torch.int64 or tuple(target.shape) != (B, H, W):
+            raise _lib.MrfpHipError("cross_entropy: target must be int64 [B,H,W]")
+        npix = B * H * W
+        nblk = int(_lib.lib().mrfp_ce_nblocks(npix))
+        ws = torch.empty(2 * nblk, dtype=torch.float32, device=logits.device)
+        loss = torch.empty(2, dtype=torch.float32, device=logits.device)
+        call("mrfp_ce_fwd", ptr(logits), ptr(target), dt(logits), npix, C, int(ignore_index), ptr(ws), ptr(loss), stream())
+        ctx.save_for_backward(logits, target, loss)
+        ctx.ignore = int(ignore_index)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, loss = ctx.saved_tensors
+        B, C, H, W = logits.shape
+        gs = g.detach().float().reshape(1).contiguous()
+        d = torch.empty_like(logits, memory_format=CL)
+        call("mrfp_ce_bwd", ptr(logits), ptr(target), ptr(loss), ptr(gs), ptr(d), dt(logits), B * H * W, C, ctx.ignore, stream())
+        return d, None, None
+
+
+def cross_entropy(logits, target, ignore_index=255):
+    return _CrossEntropy.apply(logits, target, ignore_index)
+
+
+# ------------------------------------------------------------------------------------------
+# eval: arg-max + confusion histogram on the device
+# ------------------------------------------------------------------------------------------
+def argmax_hist(logits, target, hist: Optional[torch.Tensor] = None, want_pred=False):
+    """reference main.py:898-909 + metrics.fast_hist (metrics.py:122-126), without the two full-logit
+    D2H copies: returns (hist int64 [C,C] on device, pred uint8 [B,H,W] or None)."""
+    logits = _chk(logits.detach(), "logits")
+    B, C, H, W = logits.shape
+    if hist is None:
+        hist = torch.zeros(C, C, dtype=torch.int64, device=logits.device)
+    pred = torch.empty(B, H, W, dtype=torch.uint8, device=logits.device) if want_pred else None
+    tg = target.contiguous() if target is not None else None
+    call("mrfp_argmax_hist", ptr(logits), ptr(tg), dt(logits), B * H * W, C, ptr(hist), ptr(pred), stream())
+    return hist, pred
+
+
+# ------------------------------------------------------------------------------------------
+# ReLU, input staging, convolution
+# ------------------------------------------------------------------------------------------
+class _ReLU(torch.autograd.Function):
+    """Stand-alone ReLU (only the iw=1/2/5 paths need it; BN/IN fold theirs into the apply pass)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        y = _affine_fwd(x, None, None, None, False, True, None)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        dx, _ = _affine_bwd(dy, None, y, None, None, None, False, None, False, y)
+        return dx
+
+
+def relu(x):
+    return _ReLU.apply(x)
+
+
+def as_activation(x: torch.Tensor) -> torch.Tensor:
+    """Network input -> NHWC storage in the configured activation dtype (cfg.MODEL.ACT_DTYPE)."""
+    from .config import cfg
+    if not x.is_cuda:
+        raise _lib.MrfpHipError("input must live on the GPU (got %s): the HIP path has no CPU fallback" % x.device)
+    if cfg.MODEL.CONV_BACKEND == "hip":     # one kernel: NCHW fp32 -> NHWC act dtype, channels padded to a chunk
+        from . import conv
+        return conv.pad_input_channels(x, cfg.MODEL.ACT_DTYPE)
+    if x.dtype != cfg.MODEL.ACT_DTYPE:
+        x = x.to(cfg.MODEL.ACT_DTYPE)
+    return to_cl(x)
+
+
+def conv2d(x, weight, bias, stride, padding, dilation, phys_out=None):
+    """nn.Conv2d forward/backward.  Backend 'hip': MFMA implicit-GEMM kernels (mrfp_amd/conv.py);
+    backend 'miopen': stock ROCm convolution through ATen on the same NHWC tensors (BASELINE.json
+    configs[1] "stock ROCm convs").  phys_out (hip only): return the channel-padded output buffer."""
+    from .config import cfg
+    x = _chk(x)
+    if cfg.MODEL.CONV_BACKEND == "hip":
+        from . import conv
+        return conv.conv2d(x, weight, bias, stride, padding, dilation, phys_out)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    b = bias if bias is None or bias.dtype == x.dtype else bias.to(x.dtype)
+    return torch.nn.functional.conv2d(x, w.contiguous(memory_format=CL), b, stride, padding, dilation)
+
+
+def concat_channels(tensors):
+    """torch.cat(dim=1) of NHWC activations (reference deepv3.py:125, 353).  A strided copy: pure
+    data movement by the allocator-side runtime, no arithmetic."""
+    return torch.cat([_chk(t) for t in tensors], 1).contiguous(memory_format=CL)

@@ -222,13 +222,22 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
     h, w = int(x.shape[2]), int(x.shape[3])
     taps = taps if taps is not None else {}
 
-    # stem: conv7x7 s2 -> InstanceNorm(affine) -> ReLU -> maxpool3x3 s2 (deepv3.py:309-315)
-    t = conv(sd, "layer0.0", x, stride=2, padding=3)
-    if "layer0.1.running_mean" in sd:           # plain trunk (wt_layer[2]==0): BatchNorm stem
-        t = batch_norm(sd, "layer0.1", t, bn_train, new_stats)
+    def norm(key, v):       # BatchNorm when running statistics exist in the state dict, else InstanceNorm
+        if key + ".running_mean" in sd:
+            return batch_norm(sd, key, v, bn_train, new_stats)
+        return instance_norm(sd, key, v)
+
+    if "layer0.3.weight" in sd:
+        # deep stem of ResNet3X3 (reference Resnet.py:350-435, 475-496): three 3x3 convs; layer0 =
+        # Sequential(conv1,bn1,relu1,conv2,bn2,relu2,conv3,bn3,relu3,maxpool) -- a build-defined composition
+        # for trunk='resnet-101' (the reference's MRFPPlus only accepts resnet-50)
+        t = F.relu(norm("layer0.1", conv(sd, "layer0.0", x, stride=2, padding=1)))
+        t = F.relu(norm("layer0.4", conv(sd, "layer0.3", t, padding=1)))
+        t = F.relu(norm("layer0.7", conv(sd, "layer0.6", t, padding=1)))
     else:
-        t = instance_norm(sd, "layer0.1", t)
-    t = F.max_pool2d(F.relu(t), 3, 2, 1)
+        # stem: conv7x7 s2 -> InstanceNorm(affine) -> ReLU -> maxpool3x3 s2 (deepv3.py:309-315)
+        t = F.relu(norm("layer0.1", conv(sd, "layer0.0", x, stride=2, padding=3)))
+    t = F.max_pool2d(t, 3, 2, 1)
     xp = t
     taps["stem"] = xp
     if npp:
@@ -238,19 +247,21 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
         oc_dec, oc = hrfp_branch(sd, xp, h, w, bn_train, new_stats, taps)
         if o1:
             t = oc + t
-    iw_l1 = 4 if "layer1.2.instance_norm_layer.weight" in sd else 0
-    iw_l2 = 4 if "layer2.3.instance_norm_layer.weight" in sd else 0
-    t = _stage(sd, "layer1", 64, 3, 1, 1, t, iw_l1, bn_train, new_stats)
+    nblk = {n: sum(1 for k in sd if k.startswith(n + ".") and k.endswith(".conv1.weight")) for n in
+            ("layer1", "layer2", "layer3", "layer4")}
+    iw_l1 = 4 if "layer1.%d.instance_norm_layer.weight" % (nblk["layer1"] - 1) in sd else 0
+    iw_l2 = 4 if "layer2.%d.instance_norm_layer.weight" % (nblk["layer2"] - 1) in sd else 0
+    t = _stage(sd, "layer1", 64, nblk["layer1"], 1, 1, t, iw_l1, bn_train, new_stats)
     if npp:
         t = np_plus(t, noise["np2_alpha"], noise["np2_beta"])
     low = t
     taps["layer1"] = low
-    t = _stage(sd, "layer2", 128, 4, 2, 1, t, iw_l2, bn_train, new_stats)
+    t = _stage(sd, "layer2", 128, nblk["layer2"], 2, 1, t, iw_l2, bn_train, new_stats)
     taps["layer2"] = t
-    t = _stage(sd, "layer3", 256, 6, 2, 1, t, 0, bn_train, new_stats)
+    t = _stage(sd, "layer3", 256, nblk["layer3"], 2, 1, t, 0, bn_train, new_stats)
     taps["layer3"] = t
     # D16: layer4 conv2 dilation 2 / stride 1, downsample stride 1 (deepv3.py:184-189)
-    t = _stage(sd, "layer4", 512, 3, 1, 2, t, 0, bn_train, new_stats)
+    t = _stage(sd, "layer4", 512, nblk["layer4"], 1, 2, t, 0, bn_train, new_stats)
     taps["layer4"] = t
 
     t = aspp(sd, t, bn_train, new_stats)

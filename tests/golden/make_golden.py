@@ -174,6 +174,18 @@ def main():
         print(f"[{tag}] loss ref {loss_ref.item():.6f} oracle {loss_o.item():.6f} rel {r_loss:.2e} "
               f"logits rel {r_log:.2e} worst grad rel {worst:.2e}")
 
+        # conditioning of this configuration: the reference's fp32 result against an fp64 evaluation of the
+        # same graph (batch 2 -> the ASPP image-pooling BatchNorm normalises over 2 samples and amplifies
+        # rounding noise).  Stored so that tests can scale their tolerance to what fp32 can deliver at all.
+        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        taps64 = {}
+        with torch.no_grad():
+            loss64 = orc.mrfp_forward(sd64, x.double(), y, training=True, toggles=tg,
+                                      noise={k: v.double() for k, v in noise.items()}, taps=taps64)
+        out[f"{tag}_loss64"] = np.float64(loss64.item())
+        out[f"{tag}_logits_noise"] = np.float64(rel(cap["logits"], taps64["logits"]))
+        out[f"{tag}_logits_crop64"] = taps64["logits"][CROP].numpy()
+        print(f"      fp32-vs-fp64 logits max-rel {out[f'{tag}_logits_noise']:.2e}")
         out[f"{tag}_loss"] = np.float64(loss_ref.item())
         out[f"{tag}_logits_stats"] = stats(cap["logits"])
         out[f"{tag}_logits_crop"] = cap["logits"].detach()[CROP].numpy()

@@ -1,0 +1,82 @@
+"""No-GPU checks of the boundary: the C-ABI library builds, loads, and exports every symbol that
+include/mrfp_hip.h declares; host-only entry points answer; the product path refuses to run
+without a GPU instead of falling back."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from mrfp_amd import _lib, build
+
+
+@pytest.fixture(scope="module")
+def cdll():
+    build.build()
+    return _lib.lib()
+
+
+def test_header_symbols_exported(cdll):
+    protos = _lib.parse_header()
+    assert len(protos) >= 24
+    for name in protos:
+        assert hasattr(cdll, name), name
+    assert cdll.mrfp_version() >= 100
+
+
+def test_host_only_entry_points(cdll):
+    assert cdll.mrfp_stats_nslab(16, 384) == 256
+    assert cdll.mrfp_stats_nslab(2, 64) == 64
+    assert 1 <= cdll.mrfp_ce_nblocks(10) <= 2048 and cdll.mrfp_ce_nblocks(1 << 30) == 2048
+    # argument validation happens on the host before any launch
+    rc = cdll.mrfp_add(None, None, None, 0, 0, None)
+    assert rc != 0 and b"add" in cdll.mrfp_last_error()
+
+
+def test_nearest_tables_match_aten():
+    """The host-side index tables the kernels consume == F.interpolate(mode='nearest')."""
+    import numpy as np
+    import torch.nn.functional as F
+    from mrfp_amd import ops
+    for size, kw in [(192, dict(scale=1.205)), (231, dict(scale=1.2)), (277, dict(scale=1.2)), (332, dict(size=384)),
+                     (384, dict(scale=0.838)), (321, dict(scale=0.798)), (256, dict(size=192)), (64, dict(scale=1.205)),
+                     (616, dict(scale=1.2)), (1024, dict(scale=0.838))]:
+        probe = torch.arange(size, dtype=torch.float32).view(1, 1, 1, size)
+        if "scale" in kw:
+            ref = F.interpolate(probe, scale_factor=(1.0, kw["scale"])).flatten().long().numpy()
+            out = ops.nearest_out_size(size, kw["scale"])
+            tab = ops._nearest_table(size, out, kw["scale"])
+        else:
+            ref = F.interpolate(probe, size=(1, kw["size"])).flatten().long().numpy()
+            out = kw["size"]
+            tab = ops._nearest_table(size, out, None)
+        assert out == len(ref)
+        np.testing.assert_array_equal(tab, ref)
+        inv = ops._inverse_table(tab, size).reshape(-1, 2)
+        for s in range(size):
+            assert (tab[inv[s, 0]:inv[s, 1]] == s).all() and (inv[s, 1] - inv[s, 0]) == (tab == s).sum()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_refuses_cpu():
+    from mrfp_amd.deepv3 import MRFPPlus
+    m = MRFPPlus(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
+    with pytest.raises(_lib.MrfpHipError):
+        m(torch.zeros(2, 3, 64, 64), torch.zeros(2, 64, 64, dtype=torch.long))
+
+
+def test_state_dict_abi():
+    """Same 431 keys / shapes / trainable set as the reference module (checkpoint ABI)."""
+    import json
+    from mrfp_amd.deepv3 import MRFPPlus, simpleDeepV3Plus
+    spec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_spec.json")))
+    m = MRFPPlus(19)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == spec["MRFPPlus"]
+    assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == sorted(spec["trainable"])
+    assert sorted(n for n, p in m.named_parameters() if not p.requires_grad) == sorted(spec["frozen"])
+    p = simpleDeepV3Plus(19)
+    assert [[k, list(v.shape)] for k, v in p.state_dict().items()] == spec["simpleDeepV3Plus"]
+    with pytest.raises(ValueError):
+        MRFPPlus(19, trunk="resnet-18")
+    with pytest.raises(ValueError):
+        simpleDeepV3Plus(19, trunk="resnet-101")

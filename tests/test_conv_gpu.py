@@ -1,0 +1,99 @@
+"""MFMA implicit-GEMM convolution (fwd / dgrad / wgrad, through the C ABI) against torch's fp32
+convolution on the CPU, for every (channels, kernel, stride, dilation) family of the network.
+
+fp32: v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain -> 1e-5 relative to the tensor max.
+bf16: inputs are rounded to bf16 first (so only accumulation-order and output rounding differ) -> 1e-2.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# (B, Cin, H, W, Cout, k, stride, pad, dil, bias)
+CASES = [
+    (2, 3, 40, 36, 64, 7, 2, 3, 1, False),       # stem (channel-padded input, no dgrad)
+    (2, 64, 20, 18, 64, 1, 1, 0, 1, False),      # bottleneck 1x1
+    (2, 64, 20, 18, 64, 3, 1, 1, 1, True),       # HRFP 3x3 + bias, Cout 64 -> 256x64 tile
+    (2, 64, 19, 23, 128, 3, 1, 2, 2, True),      # HRFP dilated
+    (1, 128, 17, 17, 256, 3, 1, 2, 2, True),
+    (2, 128, 16, 16, 128, 3, 2, 1, 1, False),    # strided 3x3 (layer2.0.conv2)
+    (2, 256, 16, 16, 512, 1, 2, 0, 1, False),    # strided 1x1 downsample
+    (2, 256, 9, 9, 256, 3, 1, 6, 6, False),      # ASPP dilation 6 (> feature size: mostly padding)
+    (1, 512, 8, 8, 256, 3, 1, 12, 12, False),
+    (2, 304, 12, 10, 256, 3, 1, 1, 1, False),    # decoder concat 48+256
+    (2, 256, 12, 10, 48, 1, 1, 0, 1, False),     # bot_fine
+    (2, 256, 12, 10, 19, 1, 1, 0, 1, True),      # final2 (N padded to a chunk)
+    (3, 64, 33, 31, 64, 3, 1, 1, 1, False),      # M not a multiple of the tile
+]
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(dtype, case):
+    from mrfp_amd import conv, ops
+    B, Cin, H, W, Cout, k, st, pad, dil, has_bias = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bc = b.clone().requires_grad_(True) if has_bias else None
+    yc = F.conv2d(xc, wc, bc, st, pad, dil)
+    gy = torch.randn(yc.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yc.backward(gy)
+
+    stem = Cin == 3
+    if stem:
+        xd = conv.pad_input_channels(x.to(DEV), dtype)
+    else:
+        xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if has_bias else None
+    yd = conv.conv2d(xd, wd, bd, st, pad, dil)
+    assert tuple(yd.shape) == tuple(yc.shape)
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert relerr(yd, yc) < tol
+    if not stem:
+        assert relerr(xd.grad, xc.grad) < tol
+    assert relerr(wd.grad, wc.grad) < tol * (1 if dtype == torch.float32 else 2)
+    if has_bias:
+        assert relerr(bd.grad, bc.grad) < tol
+    # weight pack cache follows in-place updates of the master weight
+    with torch.no_grad():
+        wd.mul_(0.5)
+    y2 = conv.conv2d(xd.detach(), wd, bd, st, pad, dil)
+    y2c = F.conv2d(x, w * 0.5, b, st, pad, dil)
+    assert relerr(y2, y2c) < tol
+
+
+def test_padded_logits_path():
+    """final2 with the 32-channel padded low-resolution buffer + bilinear on the first 19 channels."""
+    from mrfp_amd import conv, ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 256, 12, 10, generator=g)
+    w = torch.randn(19, 256, 1, 1, generator=g) * 0.1
+    b = torch.randn(19, generator=g) * 0.1
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yc = F.interpolate(F.conv2d(xc, wc, bc), size=(48, 40), mode="bilinear", align_corners=True)
+    gy = torch.randn(yc.shape, generator=g)
+    yc.backward(gy)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    p = conv.conv2d(xd, wd, bd, 1, 0, 1, phys_out=32)
+    assert tuple(p.shape) == (2, 32, 12, 10) and float(p.detach()[:, 19:].abs().max()) == 0.0
+    yd = ops.upsample_bilinear(p, (48, 40), channels=19)
+    yd.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+    assert relerr(yd, yc) < 1e-5 and relerr(xd.grad, xc.grad) < 1e-5
+    assert relerr(wd.grad, wc.grad) < 1e-5 and relerr(bd.grad, bc.grad) < 1e-5

@@ -1,0 +1,279 @@
+"""HIP kernels (through the C ABI / mrfp_amd.ops) against the plain PyTorch fp32 restatement of the
+same reference arithmetic, computed on the CPU (oracle/mrfp_oracle.py helpers + torch.nn.functional).
+
+fp32 activations: tolerance 2e-5 relative to the tensor's max (fp32 summation-order noise);
+bf16 activations: 2e-2 (bf16 has 8 bits of mantissa; statistics are still accumulated in fp32).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mrfp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def ops():
+    from mrfp_amd import ops as o
+    return o
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2.5e-2
+
+
+def rnd(*shape, seed=0, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale + shift
+
+
+def dev(x, dtype):
+    return x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+SHAPES = [(2, 64, 17, 23), (3, 48, 9, 31), (2, 256, 12, 12), (2, 2048, 5, 7), (1, 19, 13, 11)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_batch_norm_act(dtype, shape, relu, res):
+    o = ops()
+    B, C, H, W = shape
+    x = rnd(*shape, seed=1, scale=3.0, shift=1.5)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    r = rnd(*shape, seed=2) if res else None
+    if r is not None and dtype == torch.bfloat16:
+        r = r.bfloat16().float()
+    w, b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    gy = rnd(*shape, seed=3)
+    # CPU fp32 restatement
+    xc = x.clone().requires_grad_(True)
+    wc, bc = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rc = r.clone().requires_grad_(True) if res else None
+    rm_c, rv_c = rm.clone(), rv.clone()
+    yc = F.batch_norm(xc, rm_c, rv_c, wc, bc, True, 0.1, 1e-5)
+    if res:
+        yc = yc + rc
+    if relu:
+        yc = F.relu(yc)
+    yc.backward(gy)
+    # HIP
+    xd = dev(x, dtype)
+    rd = dev(r, dtype) if res else None
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    yd = o.batch_norm_act(xd, wd, bd, rm_d, rv_d, training=True, relu=relu, res=rd)
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    t = tol(dtype)
+    assert relerr(yd, yc) < t
+    assert relerr(rm_d, rm_c) < 1e-5 and relerr(rv_d, rv_c) < 1e-5 + (0 if dtype == torch.float32 else 1e-2)
+    assert relerr(xd.grad, xc.grad) < 10 * t
+    assert relerr(wd.grad, wc.grad) < 10 * t and relerr(bd.grad, bc.grad) < 10 * t
+    if res:
+        assert relerr(rd.grad, rc.grad) < t
+    # eval mode coefficients
+    ye = o.batch_norm_act(xd.detach(), wd.detach(), bd.detach(), rm_d, rv_d, training=False, relu=relu)
+    yec = F.batch_norm(x, rm_c, rv_c, w, b, False, 0.1, 1e-5)
+    assert relerr(ye, F.relu(yec) if relu else yec) < t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", SHAPES[:4])
+@pytest.mark.parametrize("relu,affine", [(False, True), (True, True), (False, False)])
+def test_instance_norm_act(dtype, shape, relu, affine):
+    o = ops()
+    B, C, H, W = shape
+    x = rnd(*shape, seed=4, scale=50.0, shift=120.0)       # stem-like magnitudes (inputs are 0..255)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    w = (torch.rand(C) + 0.5) if affine else None
+    b = (torch.randn(C) * 0.1) if affine else None
+    gy = rnd(*shape, seed=5)
+    xc = x.clone().requires_grad_(True)
+    wc = w.clone().requires_grad_(True) if affine else None
+    bc = b.clone().requires_grad_(True) if affine else None
+    yc = F.instance_norm(xc, None, None, wc, bc, True, 0.1, 1e-5)
+    if relu:
+        yc = F.relu(yc)
+    yc.backward(gy)
+    xd = dev(x, dtype)
+    wd = w.to(DEV).requires_grad_(True) if affine else None
+    bd = b.to(DEV).requires_grad_(True) if affine else None
+    yd = o.instance_norm_act(xd, wd, bd, relu=relu)
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    t = tol(dtype)
+    assert relerr(yd, yc) < t * (1 if dtype == torch.float32 else 2)
+    assert relerr(xd.grad, xc.grad) < 20 * t
+    if affine:
+        assert relerr(wd.grad, wc.grad) < 10 * t and relerr(bd.grad, bc.grad) < 10 * t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (4, 256, 9, 13), (16, 64, 6, 5)])
+def test_np_plus(dtype, shape):
+    o = ops()
+    B, C, H, W = shape
+    x = rnd(*shape, seed=6, scale=2.0) + rnd(B, C, 1, 1, seed=7, scale=3.0)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    alpha = 1 + 0.75 * rnd(B, C, 1, 1, seed=8)
+    beta = 0.75 * rnd(B, C, 1, 1, seed=9)
+    gy = rnd(*shape, seed=10)
+    xc = x.clone().requires_grad_(True)
+    yc = orc.np_plus(xc, alpha, beta)
+    yc.backward(gy)
+    xd = dev(x, dtype)
+    yd = o.np_plus(xd, alpha.to(DEV), beta.to(DEV))
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    t = tol(dtype)
+    assert relerr(yd, yc) < t
+    assert relerr(xd.grad, xc.grad) < 10 * t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [((2, 64, 12, 12), dict(scale=1.205)), ((2, 64, 14, 19), dict(scale=1.2)),
+                                  ((2, 128, 21, 21), dict(size=(24, 24))), ((2, 64, 24, 24), dict(scale=0.838)),
+                                  ((2, 64, 20, 20), dict(scale=0.798)), ((1, 256, 83, 83), dict(size=(96, 96)))])
+def test_hrfp_stage_resize_bn_relu(dtype, case):
+    """nearest resize -> BN(train) -> ReLU fused, against F.interpolate + F.batch_norm + relu."""
+    o = ops()
+    shape, rs = case
+    B, C, H, W = shape
+    x = rnd(*shape, seed=11, scale=2.0, shift=0.3)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    w, b = torch.randn(C) * 0.5, torch.zeros(C)
+    xc = x.clone().requires_grad_(True)
+    if "scale" in rs:
+        up = F.interpolate(xc, scale_factor=(rs["scale"], rs["scale"]))
+    else:
+        up = F.interpolate(xc, size=rs["size"])
+    yc = F.relu(F.batch_norm(up, None, None, w, b, True, 0.1, 1e-5))
+    gy = rnd(*yc.shape, seed=12)
+    yc.backward(gy)
+    xd = dev(x, dtype)
+    plan = o.nearest_plan(H, W, device=DEV, **rs)
+    assert (plan.Ho, plan.Wo) == tuple(yc.shape[2:])
+    yd = o.batch_norm_act(xd, w.to(DEV), b.to(DEV), None, None, training=True, relu=True, plan=plan)
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    t = tol(dtype)
+    assert relerr(yd, yc) < t
+    assert relerr(xd.grad, xc.grad) < 10 * t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [((2, 256, 1, 1), (7, 9), False), ((2, 256, 6, 6), (24, 24), False),
+                                  ((2, 19, 24, 20), (96, 80), False), ((1, 256, 12, 12), (24, 24), True),
+                                  ((2, 64, 5, 7), (5, 7), False), ((1, 8, 9, 9), (4, 5), False)])
+def test_bilinear(dtype, case):
+    o = ops()
+    shape, size, with_add = case
+    x = rnd(*shape, seed=13)
+    add = rnd(shape[0], shape[1], *size, seed=14) if with_add else None
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        add = add.bfloat16().float() if with_add else None
+    xc = x.clone().requires_grad_(True)
+    ac = add.clone().requires_grad_(True) if with_add else None
+    yc = orc.upsample_bilinear_ac(xc, size)
+    if with_add:
+        yc = ac + yc
+    gy = rnd(*yc.shape, seed=15)
+    yc.backward(gy)
+    xd = dev(x, dtype)
+    ad = dev(add, dtype) if with_add else None
+    yd = o.upsample_bilinear(xd, size, addend=ad)
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    t = tol(dtype)
+    assert relerr(yd, yc) < t
+    assert relerr(xd.grad, xc.grad) < 4 * t
+    if with_add:
+        assert relerr(ad.grad, ac.grad) < t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (2, 64, 17, 13), (1, 8, 1, 1), (2, 128, 2, 5)])
+def test_maxpool(dtype, shape):
+    o = ops()
+    x = rnd(*shape, seed=16)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xc = x.clone().requires_grad_(True)
+    yc = F.max_pool2d(xc, 3, 2, 1)
+    gy = rnd(*yc.shape, seed=17)
+    yc.backward(gy)
+    xd = dev(x, dtype)
+    yd = o.max_pool_3x3_s2(xd)
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    assert relerr(yd, yc) == 0.0
+    assert relerr(xd.grad, xc.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_global_avg_pool_add_relu(dtype):
+    o = ops()
+    x = rnd(2, 256, 7, 9, seed=18)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xc = x.clone().requires_grad_(True)
+    yc = F.adaptive_avg_pool2d(xc, 1)
+    gy = rnd(2, 256, 1, 1, seed=19)
+    yc.backward(gy)
+    xd = dev(x, dtype)
+    yd = o.global_avg_pool(xd)
+    yd.backward(gy.to(DEV, dtype))
+    assert relerr(yd, yc) < tol(dtype) and relerr(xd.grad, xc.grad) < tol(dtype)
+    a, b = dev(rnd(2, 48, 5, 5, seed=20), dtype), dev(rnd(2, 48, 5, 5, seed=21), dtype)
+    s = o.relu(o.add(a, b))
+    s.backward(torch.ones_like(s))
+    ref = F.relu(a.detach().float() + b.detach().float())
+    assert relerr(s, ref) < tol(dtype)
+    assert relerr(a.grad, (ref > 0).float()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 19, 24, 20), (1, 19, 7, 5)])
+def test_cross_entropy_and_hist(dtype, shape):
+    o = ops()
+    B, C, H, W = shape
+    x = rnd(*shape, seed=22, scale=3.0)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    g = torch.Generator().manual_seed(23)
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    y[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    xc = x.clone().requires_grad_(True)
+    lc = orc.cross_entropy_255(xc, y)
+    (lc * 1.7).backward()
+    xd = dev(x, dtype)
+    ld = o.cross_entropy(xd, y.to(DEV), 255)
+    (ld * 1.7).backward()
+    assert abs(ld.item() - lc.item()) / abs(lc.item()) < 1e-5
+    assert relerr(xd.grad, xc.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    hist, pred = o.argmax_hist(xd, y.to(DEV), want_pred=True)
+    ref_pred = x.numpy().argmax(1)
+    np.testing.assert_array_equal(pred.cpu().numpy(), ref_pred)
+    np.testing.assert_array_equal(hist.cpu().numpy(), orc.fast_hist(ref_pred.flatten(), y.numpy().flatten(), C))
+    # all-ignored batch -> NaN like torch
+    l2 = o.cross_entropy(xd.detach(), torch.full((B, H, W), 255, dtype=torch.long, device=DEV), 255)
+    assert math.isnan(l2.item())
+
+
+def test_cpu_input_fails_loudly():
+    from mrfp_amd import _lib
+    o = ops()
+    with pytest.raises(_lib.MrfpHipError):
+        o.relu(torch.zeros(1, 8, 2, 2))

@@ -1,0 +1,45 @@
+"""Debug aid: per-stage relative error of the HIP model against the live CPU oracle (C1 shape)."""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mrfp_amd import synth, deepv3, ops
+from mrfp_amd.config import cfg
+from oracle import mrfp_oracle as orc
+
+backend = sys.argv[1] if len(sys.argv) > 1 else "miopen"
+cfg.MODEL.CONV_BACKEND = backend
+SPEC = json.load(open(os.path.join(ROOT, "tests/golden/state_dict_spec.json")))
+sd = synth.synth_state_dict([(k, tuple(s)) for k, s in SPEC["MRFPPlus"]], seed=0)
+model = deepv3.MRFPPlus(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
+model.load_state_dict(sd); model = model.to("cuda:0").train()
+x, y = synth.synth_batch(2, 256, 256, seed=1)
+noise = synth.synth_noise(2, seed=2)
+model.rng = deepv3.InjectedRandom((True, True, True), noise)
+got = {}
+def hook(name):
+    def f(mod, inp, out):
+        got[name] = (out[0] if isinstance(out, (list, tuple)) else out).detach().float().cpu()
+    return f
+model.layer0[0].register_forward_hook(hook("conv1"))
+model.layer1.register_forward_hook(hook("layer1_pre_np"))
+model.layer2.register_forward_hook(hook("layer2"))
+model.layer3.register_forward_hook(hook("layer3"))
+model.layer4.register_forward_hook(hook("layer4"))
+model.aspp.register_forward_hook(hook("aspp"))
+model.final2.register_forward_hook(hook("final2"))
+for i in range(1, 5):
+    getattr(model, "OClayer%d" % i).register_forward_hook(hook("occonv%d" % i))
+cap = {}
+orig = model._loss
+model._loss = lambda out, g: (cap.__setitem__("logits", out.detach().float().cpu()), orig(out, g))[1]
+loss = model(x.cuda(), y.cuda(), training=True)
+taps = {}
+lo = orc.mrfp_forward({k: v.clone() for k, v in sd.items()}, x, y, training=True, toggles=(True,)*3, noise=noise, taps=taps)
+def rel(a, b): return ((a.double()-b.double()).abs().max()/b.double().abs().max()).item()
+print("loss", loss.item(), lo.item())
+c1 = torch.nn.functional.conv2d(x, sd["layer0.0.weight"], None, 2, 3)
+print("conv1", rel(got["conv1"], c1))
+for k in ("layer2", "layer3", "layer4", "aspp"):
+    print(k, rel(got[k], taps[k]), "mean diff", (got[k].double()-taps[k].double()).mean().item())
+print("logits", rel(cap["logits"], taps["logits"]), "mean diff", (cap["logits"].double()-taps["logits"].double()).mean().item())
