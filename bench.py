@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--backend", default="hip", choices=["hip", "miopen"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--dump-convs", default=None, help="write per-launch conv shapes/timings (JSON) here")
     return ap.parse_args()
 
 
@@ -194,7 +195,7 @@ def conv_roofline(model, trainer, x, y, args):
     import mrfp_amd.conv as conv_mod
     from mrfp_amd import _lib
     timer = HipTimer()
-    events, flops = [], []
+    events, flops, shapes = [], [], []
     orig = _lib.call
     st = torch.cuda.current_stream().cuda_stream
 
@@ -212,6 +213,7 @@ def conv_roofline(model, trainer, x, y, args):
             timer.record(e1, st)
             events.append((e0, e1))
             flops.append(f)
+            shapes.append((name, [int(v) for v in a[5:20]]))
             return r
         return orig(name, *a)
     conv_mod.call = spy
@@ -222,6 +224,10 @@ def conv_roofline(model, trainer, x, y, args):
         conv_mod.call = orig
     ms = [timer.elapsed_ms(a, b) for a, b in events]
     tot_ms, tot_f = sum(ms), sum(flops)
+    if args.dump_convs:
+        with open(args.dump_convs, "w") as f:
+            json.dump([{"name": n, "args": sh, "ms": m, "tflops": fl / (m * 1e-3) / 1e12 if m > 0 else 0, "gflop": fl / 1e9}
+                       for (n, sh), m, fl in zip(shapes, ms, flops)], f)
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     ach = tot_f / (tot_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(ms),

@@ -109,9 +109,10 @@ template <typename T> inline int pick_vec(int64_t C) {
 }
 
 inline int lines_per_image(int64_t B, int64_t Ho) {
-    // ~4096 workgroups in flight over the chip (256 CUs x 8 XCDs): enough to hide HBM latency,
-    // few enough that the partial-sum workspace stays a fraction of a percent of the tensor.
-    int64_t cap = 4096 / (B > 0 ? B : 1);
+    // ~1024 workgroups over the chip (4 per CU, 16 waves/CU, 4 independent 16-byte loads per lane in the
+    // statistics kernels): enough bytes in flight to cover HBM latency, few enough partial sums that the
+    // finalize kernels stay in the microseconds.
+    int64_t cap = 1024 / (B > 0 ? B : 1);
     if (cap < 1) cap = 1;
     return (int)(Ho < cap ? Ho : cap);
 }

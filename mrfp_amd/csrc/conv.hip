@@ -174,21 +174,52 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
         __syncthreads();
     }
 
-    // epilogue: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+    // epilogue.  MFMA 32x32 accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31], i.e. a
+    // lane owns single elements of 16 rows -- storing that directly is 2-byte scattered traffic.  Instead every
+    // wave transposes its tile through LDS (free after the K loop) 32 rows at a time and writes whole 16-byte
+    // chunks of output rows, 8 (bf16) / 4 (fp32) rows per wave-instruction, fully coalesced.
+    constexpr int EPC = 16 / (int)sizeof(T);              // elements per 16-byte chunk
+    constexpr int ROWB = 64 * (int)sizeof(T);             // bytes of one 64-column tile row
+    constexpr int EPITCH = ROWB + 16;                      // +16: the two lane halves (rows r, r+4) hit disjoint banks
+    constexpr int CPRW = ROWB / 16;                        // chunks per row (8 / 16)
+    constexpr int RPI = 64 / CPRW;                         // rows per wave-instruction (8 / 4)
+    char* const ep = smem + wave * (32 * EPITCH);          // 4.5 KB (bf16) / 8.5 KB (fp32) per wave
     T* y = reinterpret_cast<T*>(p.y);
+    const int nb = n0 + wn * 64;
+    float bv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + lr;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const int n = nb + j * 32 + lr;
+        bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.M) y[(size_t)m * p.ldy + n] = from_f<T>(acc[i][j][e] + bv);
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = from_f<T>(acc[i][j][e] + bv[j]);
+            }
+        // same-wave LDS round trip: no workgroup barrier needed, only the wave's own LDS ops must have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // also a compiler barrier (T stores vs uint4 loads)
+        const int mb = m0 + wm * 64 + i * 32;
+#pragma unroll
+        for (int k = 0; k < 32 / RPI; ++k) {
+            const int row = k * RPI + lane / CPRW, ch = lane % CPRW;
+            const int m = mb + row, n = nb + ch * EPC;
+            if (m < p.M && n < p.N) {
+                const uint4 v = *reinterpret_cast<const uint4*>(ep + row * EPITCH + ch * 16);
+                T* dst = y + (size_t)m * p.ldy + n;
+                if (n + EPC <= p.N) {
+                    *reinterpret_cast<uint4*>(dst) = v;
+                } else {
+                    const T* src = reinterpret_cast<const T*>(&v);
+                    for (int u = 0; u < EPC && n + u < p.N; ++u) dst[u] = src[u];
+                }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -548,7 +579,7 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int& wm, int& splits, in
     const int wn = 4 / wm;
     const int64_t tiles = ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
     const int64_t nkt = (M + 31) / 32;
-    int64_t sp = 2048 / tiles;
+    int64_t sp = 768 / tiles;     // ~3 workgroups per CU; every extra split costs an fp32 slab of the whole dW
     if (sp < 1) sp = 1;
     if (sp > nkt) sp = nkt;
     int64_t per = (nkt + sp - 1) / sp;        // K' tiles per split

@@ -50,24 +50,37 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
                 const int ih = g.tabH ? g.tabH[oh] : oh;
                 const T* xl = x + ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
                 const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
-                for (int ow = trow; ow < g.Wo; ow += L.rowthreads) {
-                    const int iw = g.tabW ? g.tabW[ow] : ow;
-                    float xv[VEC];
-                    load_f<T, VEC>(xl + (size_t)iw * g.C, xv);
-                    if (MODE == 0) {
+                // 4 independent pixels per trip: 4 (MODE 0) or up to 12 (MODE 1) 16-byte loads in flight per lane
+                for (int ow0 = trow; ow0 < g.Wo; ow0 += 4 * L.rowthreads) {
+                    float xv[4][VEC], dv[4][VEC], yv[4][VEC];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) { s[i] += xv[i]; q[i] += xv[i] * xv[i]; }
-                    } else {
-                        float dv[VEC];
-                        load_f<T, VEC>(dy + dl + (size_t)ow * g.C, dv);
-                        if (y != nullptr) {
-                            float yv[VEC];
-                            load_f<T, VEC>(y + dl + (size_t)ow * g.C, yv);
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) dv[i] = yv[i] > 0.f ? dv[i] : 0.f;
+                    for (int u = 0; u < 4; ++u) {
+                        const int ow = ow0 + u * L.rowthreads;
+                        if (ow < g.Wo) {
+                            const int iw = g.tabW ? g.tabW[ow] : ow;
+                            load_f<T, VEC>(xl + (size_t)iw * g.C, xv[u]);
+                            if (MODE == 1) {
+                                load_f<T, VEC>(dy + dl + (size_t)ow * g.C, dv[u]);
+                                if (y != nullptr) load_f<T, VEC>(y + dl + (size_t)ow * g.C, yv[u]);
+                            }
                         }
+                    }
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) { s[i] += dv[i]; q[i] += dv[i] * (xv[i] - mu[i]); }
+                    for (int u = 0; u < 4; ++u) {
+                        const int ow = ow0 + u * L.rowthreads;
+                        if (ow < g.Wo) {
+                            if (MODE == 0) {
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) { s[i] += xv[u][i]; q[i] += xv[u][i] * xv[u][i]; }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) {
+                                    const float d = (y != nullptr && !(yv[u][i] > 0.f)) ? 0.f : dv[u][i];
+                                    s[i] += d;
+                                    q[i] += d * (xv[u][i] - mu[i]);
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -117,12 +130,26 @@ static int launch_stats(const void* x, const void* dy, const void* y, const floa
 // ------------------------------------------------------------------------------------------
 struct Red { double s, q; };
 
+// block = (kFC channels) x (kFL partial lanes): few channels per block so that even a 64-channel layer
+// spreads over 8 workgroups, many lanes so that every thread only walks n/kFL partials (all independent loads).
+constexpr int kFC = 8, kFL = 32;
 __device__ __forceinline__ Red reduce_partials(const float* ws, int64_t first, int64_t n, int64_t C, int c, bool valid,
-                                               double (*sm)[2][32]) {
+                                               double (*sm)[2][kFC]) {
     const int ty = threadIdx.y, tx = threadIdx.x;
     double s = 0.0, q = 0.0;
     if (valid) {
-        for (int64_t p = first + ty; p < first + n; p += 8) {
+        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+        int64_t p = first + ty;
+        for (; p + 3 * kFL < first + n; p += 4 * kFL) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fs[u] = ws[((p + u * kFL) * 2 + 0) * C + c];
+                fq[u] = ws[((p + u * kFL) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += (double)fs[u]; q += (double)fq[u]; }
+        }
+        for (; p < first + n; p += kFL) {
             s += (double)ws[(p * 2 + 0) * C + c];
             q += (double)ws[(p * 2 + 1) * C + c];
         }
@@ -134,7 +161,7 @@ __device__ __forceinline__ Red reduce_partials(const float* ws, int64_t first, i
     Red r{0.0, 0.0};
     if (ty == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { r.s += sm[k][0][tx]; r.q += sm[k][1][tx]; }
+        for (int k = 0; k < kFL; ++k) { r.s += sm[k][0][tx]; r.q += sm[k][1][tx]; }
     }
     return r;
 }
@@ -142,8 +169,8 @@ __device__ __forceinline__ Red reduce_partials(const float* ws, int64_t first, i
 __global__ void bn_finalize_kernel(const float* ws, int64_t nparts, double count, int C, const float* weight,
                                    const float* bias, float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean, float* invstd, float* A, float* S) {
-    __shared__ double sm[8][2][32];
-    const int c = blockIdx.x * 32 + threadIdx.x;
+    __shared__ double sm[kFL][2][kFC];
+    const int c = blockIdx.x * kFC + threadIdx.x;
     const bool valid = c < C;
     Red r = reduce_partials(ws, 0, nparts, C, c, valid, sm);
     if (threadIdx.y == 0 && valid) {
@@ -189,8 +216,8 @@ __device__ __forceinline__ void norm_bwd_coef(double Ss, double Sq, double count
 __global__ void bn_bwd_finalize_kernel(const float* ws, int64_t nparts, double count, int C, const float* weight,
                                        const float* mean, const float* invstd, float* dweight, float* dbias,
                                        float* P, float* Q, float* R) {
-    __shared__ double sm[8][2][32];
-    const int c = blockIdx.x * 32 + threadIdx.x;
+    __shared__ double sm[kFL][2][kFC];
+    const int c = blockIdx.x * kFC + threadIdx.x;
     const bool valid = c < C;
     Red r = reduce_partials(ws, 0, nparts, C, c, valid, sm);
     if (threadIdx.y == 0 && valid) {
@@ -203,8 +230,8 @@ __global__ void bn_bwd_finalize_kernel(const float* ws, int64_t nparts, double c
 // InstanceNorm: grid (C/32, B)
 __global__ void in_finalize_kernel(const float* ws, int64_t nslab, double count, int C, const float* weight,
                                    const float* bias, float eps, float* mean, float* invstd, float* A, float* S) {
-    __shared__ double sm[8][2][32];
-    const int c = blockIdx.x * 32 + threadIdx.x, b = blockIdx.y;
+    __shared__ double sm[kFL][2][kFC];
+    const int c = blockIdx.x * kFC + threadIdx.x, b = blockIdx.y;
     const bool valid = c < C;
     Red r = reduce_partials(ws, (int64_t)b * nslab, nslab, C, c, valid, sm);
     if (threadIdx.y == 0 && valid) {
@@ -226,8 +253,8 @@ __global__ void in_finalize_kernel(const float* ws, int64_t nslab, double count,
 __global__ void in_bwd_finalize_kernel(const float* ws, int B, int64_t nslab, double count, int C, const float* weight,
                                        const float* mean, const float* invstd, float* dweight, float* dbias,
                                        float* P, float* Q, float* R) {
-    __shared__ double sm[8][2][32];
-    const int c = blockIdx.x * 32 + threadIdx.x;
+    __shared__ double sm[kFL][2][kFC];
+    const int c = blockIdx.x * kFC + threadIdx.x;
     const bool valid = c < C;
     double dw = 0.0, db = 0.0;
     for (int b = 0; b < B; ++b) {
@@ -247,8 +274,8 @@ __global__ void in_bwd_finalize_kernel(const float* ws, int B, int64_t nslab, do
 
 // plane sums -> fp32 [B][C] scaled by `scale` (mean: 1/count; raw sum: 1)
 __global__ void plane_sum_kernel(const float* ws, int64_t nslab, double scale, int C, float* out) {
-    __shared__ double sm[8][2][32];
-    const int c = blockIdx.x * 32 + threadIdx.x, b = blockIdx.y;
+    __shared__ double sm[kFL][2][kFC];
+    const int c = blockIdx.x * kFC + threadIdx.x, b = blockIdx.y;
     const bool valid = c < C;
     Red r = reduce_partials(ws, (int64_t)b * nslab, nslab, C, c, valid, sm);
     if (threadIdx.y == 0 && valid) out[(size_t)b * C + c] = (float)(r.s * scale);
@@ -401,7 +428,7 @@ int mrfp_bn_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, i
                      const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                      float* mean, float* invstd, float* A, float* S, void* stream) {
     MRFP_CHECK(ws && mean && invstd && A && S && C > 0 && count > 0, "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, ws,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + mrfp::kFC - 1) / mrfp::kFC)), dim3(mrfp::kFC, mrfp::kFL), 0, (hipStream_t)stream, ws,
                        B * nslab, (double)count, (int)C, weight, bias, eps, momentum, running_mean, running_var, mean,
                        invstd, A, S);
     MRFP_LAUNCH_CHECK();
@@ -421,7 +448,7 @@ int mrfp_bn_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t coun
                          const float* mean, const float* invstd, float* dweight, float* dbias, float* P, float* Q,
                          float* R, void* stream) {
     MRFP_CHECK(ws && mean && invstd && P && Q && R && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, ws,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + mrfp::kFC - 1) / mrfp::kFC)), dim3(mrfp::kFC, mrfp::kFL), 0, (hipStream_t)stream, ws,
                        B * nslab, (double)count, (int)C, weight, mean, invstd, dweight, dbias, P, Q, R);
     MRFP_LAUNCH_CHECK();
     return 0;
@@ -430,7 +457,7 @@ int mrfp_bn_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t coun
 int mrfp_in_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* weight,
                      const float* bias, float eps, float* mean, float* invstd, float* A, float* S, void* stream) {
     MRFP_CHECK(ws && mean && invstd && A && S && C > 0 && count > 0 && B > 0 && B < 65536, "in_finalize: bad arguments");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0,
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)((C + mrfp::kFC - 1) / mrfp::kFC), (unsigned)B), dim3(mrfp::kFC, mrfp::kFL), 0,
                        (hipStream_t)stream, ws, nslab, (double)count, (int)C, weight, bias, eps, mean, invstd, A, S);
     MRFP_LAUNCH_CHECK();
     return 0;
@@ -440,7 +467,7 @@ int mrfp_in_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t coun
                          const float* mean, const float* invstd, float* dweight, float* dbias, float* P, float* Q,
                          float* R, void* stream) {
     MRFP_CHECK(ws && mean && invstd && P && Q && R && C > 0 && count > 0, "in_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, ws,
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((unsigned)((C + mrfp::kFC - 1) / mrfp::kFC)), dim3(mrfp::kFC, mrfp::kFL), 0, (hipStream_t)stream, ws,
                        (int)B, nslab, (double)count, (int)C, weight, mean, invstd, dweight, dbias, P, Q, R);
     MRFP_LAUNCH_CHECK();
     return 0;
@@ -450,7 +477,7 @@ int mrfp_np_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, i
                      const float* beta_noise, float* mu, float* sigma, float* A, float* S, void* stream) {
     MRFP_CHECK(ws && alpha && beta_noise && mu && sigma && A && S && C > 0 && B > 0 && B < 65536, "np_finalize: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, st, ws, nslab,
+    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + mrfp::kFC - 1) / mrfp::kFC), (unsigned)B), dim3(mrfp::kFC, mrfp::kFL), 0, st, ws, nslab,
                        1.0 / (double)count, (int)C, mu);
     MRFP_LAUNCH_CHECK();
     hipLaunchKernelGGL(np_coef_kernel, dim3(1), dim3(kThreads), 0, st, (int)B, (int)C, alpha, beta_noise, mu, sigma, A, S);
@@ -463,7 +490,7 @@ int mrfp_np_bwd_finalize(const float* ws, int64_t B, int64_t nslab, int64_t coun
                          void* stream) {
     MRFP_CHECK(ws && alpha && beta_noise && mu && sigma && Gtmp && K && C > 0 && B > 0 && B < 65536, "np_bwd_finalize: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, st, ws, nslab, 1.0,
+    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + mrfp::kFC - 1) / mrfp::kFC), (unsigned)B), dim3(mrfp::kFC, mrfp::kFL), 0, st, ws, nslab, 1.0,
                        (int)C, Gtmp);
     MRFP_LAUNCH_CHECK();
     hipLaunchKernelGGL(np_bwd_coef_kernel, dim3(1), dim3(kThreads), 0, st, (int)B, (int)C, (double)count, alpha,
@@ -477,7 +504,7 @@ int mrfp_mean_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count,
     MRFP_CHECK(ws && out && tmp && C > 0 && B > 0 && B < 65536, "mean_finalize: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     float* dst = dtype == MRFP_F32 ? (float*)out : tmp;
-    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(32, 8), 0, st, ws, nslab,
+    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((C + mrfp::kFC - 1) / mrfp::kFC), (unsigned)B), dim3(mrfp::kFC, mrfp::kFL), 0, st, ws, nslab,
                        1.0 / (double)count, (int)C, dst);
     MRFP_LAUNCH_CHECK();
     if (dtype == MRFP_BF16) {
