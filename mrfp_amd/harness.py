@@ -28,28 +28,43 @@ def poly_lr_factor(it: int, max_iter: int = 40000, power: float = 0.9) -> float:
     return math.pow(1 - it / max_iter, power)
 
 
-class FlatSGD:
-    """torch.optim.SGD(lr, momentum=0.9, weight_decay=5e-4) + LambdaLR(poly 0.9) over flat arenas."""
+class FlatArena:
+    """Trainable parameters and their gradients as views into two flat fp32 buffers (every tensor starts
+    16-byte aligned).  Device-agnostic host logic: the data-parallel buckets are ranges of `flat_g`."""
 
-    def __init__(self, model: torch.nn.Module, lr=1e-2, momentum=0.9, weight_decay=5e-4, max_iter=40000, power=0.9):
+    def __init__(self, model: torch.nn.Module):
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        if dev.type != "cuda":
-            raise _lib.MrfpHipError("FlatSGD needs the model on the GPU: the HIP path has no CPU fallback")
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned inside the arena
+            n += (p.numel() + 3) // 4 * 4
         self.n = n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
             self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + p.numel()].view(p.shape)
             p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):   # keep .grad pointing into the arena
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+
+class FlatSGD(FlatArena):
+    """torch.optim.SGD(lr, momentum=0.9, weight_decay=5e-4) + LambdaLR(poly 0.9) as ONE fused HIP kernel
+    over the flat arenas (reference main.py:826-839, 863-864)."""
+
+    def __init__(self, model: torch.nn.Module, lr=1e-2, momentum=0.9, weight_decay=5e-4, max_iter=40000, power=0.9):
+        super().__init__(model)
+        if self.flat_p.device.type != "cuda":
+            raise _lib.MrfpHipError("FlatSGD needs the model on the GPU: the HIP path has no CPU fallback")
+        self.flat_m = torch.zeros_like(self.flat_p)
         self.base_lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.max_iter, self.power = max_iter, power
         self.it = 0
@@ -57,12 +72,6 @@ class FlatSGD:
     @property
     def lr(self):
         return self.base_lr * poly_lr_factor(self.it, self.max_iter, self.power)
-
-    def zero_grad(self):
-        self.flat_g.zero_()
-        for p, o in zip(self.params, self.offsets):   # autograd may have replaced .grad (first backward)
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
-                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
     def step(self, gscale: float = 1.0):
         call("mrfp_sgd_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), self.n, float(self.lr),
@@ -77,7 +86,7 @@ class FlatSGD:
 class GradSync:
     """Bucketed RCCL all-reduce of the flat gradient arena, overlapped with backward."""
 
-    def __init__(self, opt: FlatSGD, bucket_mb: float = 32.0, group=None):
+    def __init__(self, opt: FlatArena, bucket_mb: float = 32.0, group=None):
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.enabled = self.world > 1
@@ -99,7 +108,8 @@ class GradSync:
                 self.bucket_of[i] = b
         self.pending = [0] * len(self.buckets)
         self.works = []
-        self.side = torch.cuda.Stream()
+        self.on_gpu = opt.flat_g.is_cuda
+        self.side = torch.cuda.Stream() if self.on_gpu else None
         for i, p in enumerate(opt.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -113,6 +123,9 @@ class GradSync:
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
+        if not self.on_gpu:                      # gloo / CPU arenas (tests): no streams involved
+            self.works.append(dist.all_reduce(self.opt.flat_g[lo:hi], group=self.group, async_op=True))
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
@@ -134,7 +147,8 @@ class GradSync:
                 self._launch(b)
         for w in self.works:
             w.wait()
-        torch.cuda.current_stream().wait_stream(self.side)
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.side)
         return 1.0 / self.world
 
 
