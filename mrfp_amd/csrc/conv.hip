@@ -37,6 +37,7 @@ struct ConvP {
     int R, S, Ho, Wo;
     int stride, pad_h, pad_w, dil, sstride;
     int M, cpr, kchunks;
+    unsigned xbytes, wbytes;   // sizes of x and of the weight pack (buffer descriptors)
 };
 
 template <typename T> struct Mma;
@@ -66,7 +67,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <typename T, int WM, int WN>
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+// Every tensor the kernels accept is smaller than this many bytes, so a buffer load at an offset >= kOOB is
+// out of range and returns zeros: padding, M / N / K tails are all handled by the hardware bounds check of
+// buffer_load (no branches, no 64-bit address arithmetic in the K loop).
+constexpr unsigned kOOB = 0xF0000000u;
+
+__device__ __forceinline__ uint4 bload(const __amdgpu_buffer_rsrc_t& r, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// ALIGNED: the channel count fills whole K tiles (C*sizeof(T) % 128 == 0), so a K tile never straddles a
+//          filter tap and the tap (r,s) is tracked in scalar registers; otherwise every thread tracks the tap
+//          of its own 16-byte chunk.
+// STRIDED: dgrad of a strided convolution (taps exist only where the position divides the source stride).
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
     constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
@@ -81,10 +97,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int chunk = t & 7, rbase = t >> 3;
+    const int pixbytes = p.C * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
 
     // fixed per-thread gather state for its SA rows of the A tile
     int a_ih0[SA], a_iw0[SA];
-    const char* a_img[SA];
+    unsigned a_base[SA];   // !STRIDED: byte offset of pixel (b, ih0, iw0) (mod 2^32); STRIDED: offset of image b
 #pragma unroll
     for (int i = 0; i < SA; ++i) {
         const int m = m0 + rbase + i * RSTEP;
@@ -93,40 +112,67 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
             const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
             a_ih0[i] = oh * p.stride - p.pad_h;
             a_iw0[i] = ow * p.stride - p.pad_w;
-            a_img[i] = p.x + (size_t)b * p.H * p.W * p.C * sizeof(T);
+            a_base[i] = STRIDED ? (unsigned)(b * p.H * p.W) * (unsigned)pixbytes
+                                : (unsigned)((b * p.H + a_ih0[i]) * p.W + a_iw0[i]) * (unsigned)pixbytes;
         } else {
             a_ih0[i] = -(1 << 28);
-            a_iw0[i] = 0;
-            a_img[i] = p.x;
+            a_iw0[i] = -(1 << 28);
+            a_base[i] = 0;
         }
     }
-    const int pixbytes = p.C * (int)sizeof(T);
+    unsigned b_base[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        const int n = n0 + rbase + i * RSTEP;
+        b_base[i] = n < p.N ? (unsigned)n * (unsigned)p.kchunks * 16u : kOOB;
+    }
+
+    // tap tracking: scalar (r, s, tile-in-tap) when ALIGNED, per-thread (r, s, chunk-in-tap) otherwise
+    int tr = 0, ts = 0, tc = 0;
+    if (!ALIGNED) {
+        const int rs = chunk / p.cpr;
+        tc = chunk - rs * p.cpr;
+        tr = rs / p.S;
+        ts = rs - tr * p.S;
+    }
+    const int tiles_per_tap = p.cpr >> 3;
 
     auto load_tile = [&](int kt, uint4 (&ra)[SA], uint4 (&rb)[SB]) {
-        const int q = kt * 8 + chunk;
-        const int rs = q / p.cpr, cc = q - rs * p.cpr;
-        const int r = rs / p.S, s = rs - r * p.S;
-        const bool qok = q < p.kchunks;
+        const int dh = tr * p.dil, dw = ts * p.dil;
+        const int cc = ALIGNED ? tc * 8 + chunk : tc;
+        const bool qok = ALIGNED ? true : tr < p.R;
+        const unsigned tap = (unsigned)((dh * p.W + dw) * pixbytes + cc * 16);
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
-            int ih = a_ih0[i] + r * p.dil, iw = a_iw0[i] + s * p.dil;
-            bool ok = qok && ih >= 0 && iw >= 0;
-            if (p.sstride > 1) {
-                ok = ok && (ih % p.sstride == 0) && (iw % p.sstride == 0);
+            int ih = a_ih0[i] + dh, iw = a_iw0[i] + dw;
+            unsigned voff;
+            if (STRIDED) {
+                bool ok = qok && ih >= 0 && iw >= 0 && (ih % p.sstride == 0) && (iw % p.sstride == 0);
                 ih /= p.sstride;
                 iw /= p.sstride;
+                ok = ok && ih < p.H && iw < p.W;
+                voff = ok ? a_base[i] + (unsigned)((ih * p.W + iw) * pixbytes + cc * 16) : kOOB;
+            } else {
+                const bool ok = qok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                voff = ok ? a_base[i] + tap : kOOB;
             }
-            ok = ok && ih < p.H && iw < p.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(a_img[i] + (size_t)(ih * p.W + iw) * pixbytes + cc * 16);
-            ra[i] = v;
+            ra[i] = bload(xr, voff);
         }
+        const unsigned qoff = qok ? (unsigned)(kt * 8 + chunk) * 16u : kOOB;
 #pragma unroll
-        for (int i = 0; i < SB; ++i) {
-            const int n = n0 + rbase + i * RSTEP;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (qok && n < p.N) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)n * p.kchunks + q) * 16);
-            rb[i] = v;
+        for (int i = 0; i < SB; ++i) rb[i] = bload(wr, (b_base[i] >= kOOB || !qok) ? kOOB : b_base[i] + qoff);
+        // advance to the next K tile
+        if (ALIGNED) {
+            if (++tc == tiles_per_tap) {
+                tc = 0;
+                if (++ts == p.S) { ts = 0; ++tr; }
+            }
+        } else {
+            tc += 8;
+            while (tc >= p.cpr) {
+                tc -= p.cpr;
+                if (++ts == p.S) { ts = 0; ++tr; }
+            }
         }
     };
     auto store_tile = [&](int buf, const uint4 (&ra)[SA], const uint4 (&rb)[SB]) {
@@ -223,26 +269,34 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
     }
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED>
 static int launch_igemm(const ConvP& p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int lds = 2 * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds,
+                       st, p);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
 
+template <typename T, int WM, int WN>
+static int pick_igemm(const ConvP& p, hipStream_t st) {
+    const bool aligned = (p.cpr & 7) == 0, strided = p.sstride > 1;
+    if (aligned) return strided ? launch_igemm<T, WM, WN, true, true>(p, st) : launch_igemm<T, WM, WN, true, false>(p, st);
+    return strided ? launch_igemm<T, WM, WN, false, true>(p, st) : launch_igemm<T, WM, WN, false, false>(p, st);
+}
+
 template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
-    if (p.N <= 64) return launch_igemm<T, 4, 1>(p, st);
-    return launch_igemm<T, 2, 2>(p, st);
+    if (p.N <= 64) return pick_igemm<T, 4, 1>(p, st);
+    return pick_igemm<T, 2, 2>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -307,13 +361,16 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
     MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "conv_fwd: unknown dtype %d", dtype);
     MRFP_CHECK((C * esz) % 16 == 0, "conv_fwd: C=%lld must make 16-byte chunks (pad the channels)", (long long)C);
     MRFP_CHECK(aligned16(x) && aligned16(wpack), "conv_fwd: x / wpack must be 16-byte aligned");
-    MRFP_CHECK(B * Ho * Wo < (1LL << 31) && H * W * C * esz < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
+    MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
     ConvP p;
     p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
     p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    const int64_t xb = B * H * W * C * esz, wb = N * (int64_t)p.kchunks * 16;
+    MRFP_CHECK(xb < (int64_t)kOOB && wb < (int64_t)kOOB, "conv_fwd: tensor exceeds the 3.75 GB buffer-descriptor range");
+    p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
     if (dtype == MRFP_F32) return run_igemm<float>(p, (hipStream_t)stream);
     return run_igemm<bf16>(p, (hipStream_t)stream);
 }
