@@ -50,10 +50,12 @@ int mrfp_stats_fwd(const void* x, int dtype, int64_t B, int64_t Ho, int64_t Wo, 
                    int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW,
                    float* ws, void* stream);
 
-/* dy' = dy * (y > 0) when y != NULL (ReLU mask taken from the forward output), else dy.
- * mean: float [G][C] (G = B if per_image else 1) or NULL (=0). */
-int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* mean, int per_image,
-                   int dtype, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
+/* ReLU mask of the backward pass: dy' = dy * (y > 0) when y != NULL (mask from the forward output);
+ * else dy' = dy * (x*fA + fS > 0) when fA/fS != NULL (mask recomputed from x with the forward apply
+ * coefficients -- one tensor less to read); else dy' = dy.
+ * mean, fA, fS: float [G][C] (G = B if per_image else 1); mean NULL = 0. */
+int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* mean,
+                   const float* fA, const float* fS, int per_image, int dtype, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
                    int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW,
                    float* ws, void* stream);
 
@@ -106,7 +108,7 @@ int mrfp_mean_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count,
  * fwd:  y[b,oh,ow,c] = act( x[b,tabH[oh],tabW[ow],c] * A[g,c] + S[g,c] + res[b,oh,ow,c] )
  *       g = b if coef_per_image else 0;  res may be NULL;  relu = 0/1.
  *       A == NULL means A = 1 (pure broadcast add of S), x == NULL means x = 0.
- * bwd:  dy' = dy * (y > 0) if y != NULL
+ * bwd:  dy' = dy * (y > 0) if y != NULL, else dy * (x*fA + fS > 0) if fA != NULL (see mrfp_stats_bwd)
  *       dx[b,ih,iw,c] = sum over destinations mapped to (ih,iw) of P*dy'  + n*(Q*x + R)
  *       (n = number of such destinations; invH/invW give their half-open ranges:
  *        destination rows [invH[2*ih], invH[2*ih+1]) map to source row ih; NULL = identity)
@@ -120,8 +122,8 @@ int mrfp_affine_fwd(const void* x, const void* res, void* y, int dtype,
 int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int dtype,
                     int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
                     const int32_t* invH, const int32_t* invW,
-                    const float* P, const float* Q, const float* R, int coef_per_image,
-                    void* stream);
+                    const float* P, const float* Q, const float* R,
+                    const float* fA, const float* fS, int coef_per_image, void* stream);
 
 /* y = a + b, elementwise over n elements (torch.add of reference deepv3.py:330, 357). */
 int mrfp_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                                                               const int32_t* __restrict__ invH,
                                                               const int32_t* __restrict__ invW,
                                                               const float* __restrict__ P, const float* __restrict__ Q,
-                                                              const float* __restrict__ R, int coef_per_image) {
+                                                              const float* __restrict__ R, const float* __restrict__ fA,
+                                                              const float* __restrict__ fS, int coef_per_image) {
     // here g.Hs/g.Ws is the geometry of dx (the walked tensor), g.Ho/g.Wo that of dy
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
     const Lanes L = make_lanes(g.C, VEC);
@@ -77,20 +78,26 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
     if (trow >= L.rowthreads) return;
     const size_t cbase = (size_t)(coef_per_image ? b : 0) * g.C;
     for (int cv = tcol; cv < L.lpr; cv += kThreads) {
-        float p[VEC], q[VEC], r[VEC];
+        float p[VEC], q[VEC], r[VEC], fa[VEC], fs[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { p[i] = 1.f; q[i] = 0.f; r[i] = 0.f; }
+        for (int i = 0; i < VEC; ++i) { p[i] = 1.f; q[i] = 0.f; r[i] = 0.f; fa[i] = 0.f; fs[i] = 1.f; }
         if (P) load_coef<VEC>(P + cbase + (size_t)cv * VEC, p);
         if (Q) load_coef<VEC>(Q + cbase + (size_t)cv * VEC, q);
         if (R) load_coef<VEC>(R + cbase + (size_t)cv * VEC, r);
+        const bool remask = !y && fA && x;      // ReLU mask recomputed as (x*A + S) > 0 -- one tensor less to read
+        if (remask) {
+            load_coef<VEC>(fA + cbase + (size_t)cv * VEC, fa);
+            load_coef<VEC>(fS + cbase + (size_t)cv * VEC, fs);
+        }
         for (int ih = j; ih < g.Hs; ih += ly) {
             const int oh0 = invH ? invH[2 * ih] : ih, oh1 = invH ? invH[2 * ih + 1] : ih + 1;
             const size_t sl = ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
             for (int iw = trow; iw < g.Ws; iw += L.rowthreads) {
                 const int ow0 = invW ? invW[2 * iw] : iw, ow1 = invW ? invW[2 * iw + 1] : iw + 1;
-                float acc[VEC];
+                float acc[VEC], xv[VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                for (int i = 0; i < VEC; ++i) { acc[i] = 0.f; xv[i] = 0.f; }
+                if (x && (Q || remask)) load_f<T, VEC>(x + sl + (size_t)iw * g.C, xv);
                 for (int oh = oh0; oh < oh1; ++oh) {
                     const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
                     for (int ow = ow0; ow < ow1; ++ow) {
@@ -101,6 +108,9 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                             load_f<T, VEC>(y + dl + (size_t)ow * g.C, yv);
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) dv[i] = yv[i] > 0.f ? dv[i] : 0.f;
+                        } else if (remask) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) dv[i] = (xv[i] * fa[i] + fs[i] > 0.f) ? dv[i] : 0.f;
                         }
                         if (dres) store_f<T, VEC>(dres + dl + (size_t)ow * g.C, dv);
 #pragma unroll
@@ -110,8 +120,6 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                 const float n = (float)((oh1 - oh0) * (ow1 - ow0));
                 float o[VEC];
                 if (x && Q) {
-                    float xv[VEC];
-                    load_f<T, VEC>(x + sl + (size_t)iw * g.C, xv);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * (q[i] * xv[i] + r[i]);
                 } else {
@@ -159,19 +167,20 @@ static int launch_affine_fwd(const void* x, const void* res, void* y, int64_t B,
 template <typename T>
 static int launch_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t B, int64_t Ho,
                              int64_t Wo, int64_t C, int64_t Hs, int64_t Ws, const int32_t* invH, const int32_t* invW,
-                             const float* P, const float* Q, const float* R, int cpi, hipStream_t st) {
+                             const float* P, const float* Q, const float* R, const float* fA, const float* fS, int cpi,
+                             hipStream_t st) {
     RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, nullptr, nullptr};
     const int ly = lines_per_image(B, Hs);
     dim3 grid((unsigned)(B * ly));
     const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(dy) && aligned16(dx) && (!x || aligned16(x)) &&
                         (!y || aligned16(y)) && (!dres || aligned16(dres)) && (!P || aligned16(P)) &&
-                        (!Q || aligned16(Q)) && (!R || aligned16(R));
+                        (!Q || aligned16(Q)) && (!R || aligned16(R)) && (!fA || (aligned16(fA) && aligned16(fS)));
     if (vec_ok)
         hipLaunchKernelGGL((affine_bwd_kernel<T, FullVec<T>::value>), grid, dim3(kThreads), 0, st, (const T*)dy,
-                           (const T*)x, (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, cpi);
+                           (const T*)x, (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, fA, fS, cpi);
     else
         hipLaunchKernelGGL((affine_bwd_kernel<T, 1>), grid, dim3(kThreads), 0, st, (const T*)dy, (const T*)x,
-                           (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, cpi);
+                           (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, fA, fS, cpi);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
@@ -214,13 +223,15 @@ int mrfp_affine_fwd(const void* x, const void* res, void* y, int dtype, int64_t 
 
 int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int dtype, int64_t B,
                     int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws, const int32_t* invH, const int32_t* invW,
-                    const float* P, const float* Q, const float* R, int coef_per_image, void* stream) {
+                    const float* P, const float* Q, const float* R, const float* fA, const float* fS, int coef_per_image,
+                    void* stream) {
+    MRFP_CHECK(!fA == !fS, "affine_bwd: fA and fS go together");
     MRFP_CHECK(dy && dx && B > 0 && Ho > 0 && Wo > 0 && C > 0 && Hs > 0 && Ws > 0, "affine_bwd: bad arguments");
     MRFP_CHECK((invH && invW) || (Hs == Ho && Ws == Wo), "affine_bwd: resize geometry without inverse tables");
     MRFP_CHECK(!dres || (!invH && !invW), "affine_bwd: dres is not supported behind a resize");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MRFP_F32) return launch_affine_bwd<float>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, coef_per_image, st);
-    if (dtype == MRFP_BF16) return launch_affine_bwd<bf16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, coef_per_image, st);
+    if (dtype == MRFP_F32) return launch_affine_bwd<float>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
+    if (dtype == MRFP_BF16) return launch_affine_bwd<bf16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
     MRFP_CHECK(false, "affine_bwd: unknown dtype %d", dtype);
 }
 

@@ -21,6 +21,7 @@
 // Replaces (reference): every nn.Conv2d on the hot path -- Resnet.py:156-161 (Bottleneck),
 // deepv3.py:96-112 (ASPP), 200-219 (decoder), 221-237 (HRFP), and their autograd backward.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace mrfp {
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint4 bload(const __amdgpu_buffer_rsrc_t& r, unsigned
 //          filter tap and the tap (r,s) is tracked in scalar registers; otherwise every thread tracks the tap
 //          of its own 16-byte chunk.
 // STRIDED: dgrad of a strided convolution (taps exist only where the position divides the source stride).
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED>
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
     constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
     __syncthreads();
     const int lr = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+        const int buf = NBUF == 2 ? (kt & 1) : 0;
         if (kt + 1 < nkt) load_tile(kt + 1, ra, rb);
         const char* a = sA0 + buf * BUF;
         const char* b = sB0 + buf * BUF;
@@ -216,8 +217,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
-        if (kt + 1 < nkt) store_tile(buf ^ 1, ra, rb);
-        __syncthreads();
+        if (NBUF == 2) {
+            if (kt + 1 < nkt) store_tile(buf ^ 1, ra, rb);
+            __syncthreads();
+        } else {
+            // single LDS buffer (half the LDS -> one more workgroup per CU): the prefetched tile waits in
+            // registers until every wave has finished reading the current one
+            __syncthreads();
+            if (kt + 1 < nkt) store_tile(0, ra, rb);
+            __syncthreads();
+        }
     }
 
     // epilogue.  MFMA 32x32 accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31], i.e. a
@@ -269,21 +278,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
     }
 }
 
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED>
-static int launch_igemm(const ConvP& p, hipStream_t st) {
+static int g_nbuf = 0;   // 0 = pick per shape; 1 / 2 forced (MRFP_CONV_NBUF, for A/B measurements)
+
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF>
+static int launch_igemm_nb(const ConvP& p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    const int lds = 2 * (BM + BN) * 128;
+    constexpr int EP = 64 * WM * WN / 64 * 32 * (64 * (int)sizeof(T) + 16);     // epilogue staging
+    const int lds = NBUF * (BM + BN) * 128 > EP ? NBUF * (BM + BN) * 128 : EP;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds,
-                       st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF>), dim3((unsigned)tiles),
+                       dim3(64 * WM * WN), lds, st, p);
     MRFP_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED>
+static int launch_igemm(const ConvP& p, hipStream_t st) {
+    if (g_nbuf == 0) {
+        const char* e = getenv("MRFP_CONV_NBUF");
+        g_nbuf = e ? atoi(e) : 3;
+        if (g_nbuf < 1 || g_nbuf > 3) g_nbuf = 3;
+    }
+    int nb = g_nbuf;
+    if (nb == 3) nb = 1;   // default (measured on MI355X): single buffer, 3 workgroups per CU
+    return nb == 1 ? launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1>(p, st)
+                   : launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2>(p, st);
 }
 
 template <typename T, int WM, int WN>
@@ -429,6 +454,19 @@ namespace mrfp {
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((address_space(3))) short4v lds_short4v;
 
+struct FastDiv {     // exact n / d for 0 <= n < 2^31:  q = (n * m) >> (31 + l),  m = floor(2^(31+l)/d) + 1
+    unsigned m, sh;
+};
+static FastDiv make_fastdiv(unsigned d) {
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;
+    FastDiv f;
+    f.m = (unsigned)(((1ull << (31 + l)) / d) + 1);
+    f.sh = 31 + l;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)n * f.m) >> f.sh); }
+
 struct WgP {
     const char* x;    // [B,H,W,C]
     const char* dy;   // [M][ldn]
@@ -437,7 +475,9 @@ struct WgP {
     int N, ldn;       // logical output channels, physical pitch of dy (elements)
     int R, S, Ho, Wo, stride, pad_h, pad_w, dil;
     int M, Q;         // pixels, R*S*C
-    int klen;         // pixels per split (multiple of 32)
+    int klen;         // pixels per split (multiple of the K' tile)
+    unsigned xbytes, dybytes;
+    FastDiv div_hw, div_w;   // by Ho*Wo and by Wo
 };
 
 template <typename T> struct WgFrag;
@@ -474,16 +514,20 @@ template <> struct WgFrag<float> {
     static constexpr int KSTEP = 8;
 };
 
+template <typename T> struct WgTile { static constexpr int BKP = 64; };   // pixels per K' tile
+template <> struct WgTile<float> { static constexpr int BKP = 32; };
+
 template <typename T, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
     static_assert(WM * WN == 4, "4 waves");
-    constexpr int BKP = 32;                                  // pixels per K' tile
+    constexpr int BKP = WgTile<T>::BKP;
     constexpr int EPC = 16 / (int)sizeof(T);                 // elements per 16-byte chunk
     constexpr int CY = 64 * WM / EPC, CX = 64 * WN / EPC;    // chunks per tile row
     constexpr int SY = BKP * CY / 256, SX = BKP * CX / 256;  // slots per thread
     constexpr int PY = 64 * WM * (int)sizeof(T) + 64, PX = 64 * WN * (int)sizeof(T) + 64;   // row pitches
-    constexpr int BUF = BKP * (PY + PX);
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ty = smem;               // single LDS buffer: the next tile waits in registers
+    char* const tx = smem + BKP * PY;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -491,55 +535,67 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
     const int n0 = (blockIdx.x / ntq) * 64 * WM, q0 = (blockIdx.x % ntq) * 64 * WN;
     const int kbeg = blockIdx.y * p.klen;
     const int kend = min(p.M, kbeg + p.klen);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dybytes, 0x00020000);
 
-    // dY slots: dense rows
+    // dY slots: dense rows; column fixed per thread
     const int ychunk = t % CY, yrow = t / CY;
     const int yn = n0 + ychunk * EPC;
-    const bool yok = yn < p.ldn;
-    // X slots: fixed tap/channel per thread, moving pixel per slot
+    const unsigned ycol = yn < p.ldn ? (unsigned)yn * (unsigned)sizeof(T) : kOOB;
+    const unsigned yrowbytes = (unsigned)p.ldn * (unsigned)sizeof(T);
+    // X slots: fixed tap / channel per thread; the pixel moves by one K' tile per trip.  Its source coordinates
+    // (ih, iw) and byte offset are advanced incrementally with adds / selects only (no multiply, no divide).
     const int xchunk = t % CX, xrow = t / CX;
     const int q = q0 + xchunk * EPC;
-    const bool qok = q < p.Q;
     const int rs = q / p.C, c = q - rs * p.C;
     const int r = rs / p.S, s = rs - r * p.S;
-    int xb[SX], xoh[SX], xow[SX];
+    const int dh = r * p.dil - p.pad_h, dw = s * p.dil - p.pad_w;
+    const bool xcol_ok = q < p.Q;
+    const int pixbytes = p.C * (int)sizeof(T);
+    const int st = p.stride;
+    const int qh = BKP / p.Wo, rw = BKP - qh * p.Wo;                       // one K' tile = qh rows + rw pixels
+    const int d_iw = rw * st, d_ih = qh * st;
+    const unsigned D0 = (unsigned)((d_ih * p.W + d_iw) * pixbytes);        // plain advance
+    const unsigned D1 = (unsigned)((st * p.W - p.Wo * st) * pixbytes);     // output-row wrap
+    const unsigned D2 = (unsigned)((p.H * p.W - p.Ho * st * p.W) * pixbytes);   // image wrap
+    const int iw_lim = p.Wo * st + dw, ih_lim = p.Ho * st + dh, WoSt = p.Wo * st, HoSt = p.Ho * st;
+    int x_ih[SX], x_iw[SX];
+    unsigned x_off[SX];
 #pragma unroll
     for (int i = 0; i < SX; ++i) {
         const int m = kbeg + xrow + i * (256 / CX);
-        xb[i] = m / (p.Ho * p.Wo);
-        const int rem = m - xb[i] * (p.Ho * p.Wo);
-        xoh[i] = rem / p.Wo;
-        xow[i] = rem - xoh[i] * p.Wo;
+        const int b = m / (p.Ho * p.Wo), rem = m - b * (p.Ho * p.Wo);
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        x_ih[i] = oh * st + dh;
+        x_iw[i] = ow * st + dw;
+        x_off[i] = (unsigned)((b * p.H + x_ih[i]) * p.W + x_iw[i]) * (unsigned)pixbytes + (unsigned)c * (unsigned)sizeof(T);
     }
-    const int pixbytes = p.C * (int)sizeof(T);
+    unsigned y_off[SY];
+#pragma unroll
+    for (int i = 0; i < SY; ++i) y_off[i] = (unsigned)(kbeg + yrow + i * (256 / CY)) * yrowbytes + ycol;
+    const unsigned y_step = (unsigned)BKP * yrowbytes;
 
     auto load_tile = [&](int k0, uint4 (&ry)[SY], uint4 (&rx)[SX]) {
 #pragma unroll
         for (int i = 0; i < SY; ++i) {
             const int m = k0 + yrow + i * (256 / CY);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (yok && m < kend) v = *reinterpret_cast<const uint4*>(p.dy + ((size_t)m * p.ldn + yn) * sizeof(T));
-            ry[i] = v;
+            ry[i] = bload(yr, (m < kend && ycol < kOOB) ? y_off[i] : kOOB);
+            y_off[i] += y_step;
         }
 #pragma unroll
         for (int i = 0; i < SX; ++i) {
             const int m = k0 + xrow + i * (256 / CX);
-            const int ih = xoh[i] * p.stride - p.pad_h + r * p.dil, iw = xow[i] * p.stride - p.pad_w + s * p.dil;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (qok && m < kend && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(xb[i] * p.H + ih) * p.W + iw) * pixbytes + c * sizeof(T));
-            rx[i] = v;
-            // advance this slot's pixel by one K' tile
-            xow[i] += BKP;
-            while (xow[i] >= p.Wo) {
-                xow[i] -= p.Wo;
-                if (++xoh[i] == p.Ho) { xoh[i] = 0; ++xb[i]; }
-            }
+            const bool ok = xcol_ok && m < kend && (unsigned)x_ih[i] < (unsigned)p.H && (unsigned)x_iw[i] < (unsigned)p.W;
+            rx[i] = bload(xr, ok ? x_off[i] : kOOB);
+            // advance this slot by one K' tile
+            x_iw[i] += d_iw;
+            x_ih[i] += d_ih;
+            x_off[i] += D0;
+            if (x_iw[i] >= iw_lim) { x_iw[i] -= WoSt; x_ih[i] += st; x_off[i] += D1; }
+            while (x_ih[i] >= ih_lim) { x_ih[i] -= HoSt; x_off[i] += D2; }
         }
     };
-    auto store_tile = [&](int buf, const uint4 (&ry)[SY], const uint4 (&rx)[SX]) {
-        char* ty = smem + buf * BUF;
-        char* tx = ty + BKP * PY;
+    auto store_tile = [&](const uint4 (&ry)[SY], const uint4 (&rx)[SX]) {
 #pragma unroll
         for (int i = 0; i < SY; ++i) *reinterpret_cast<uint4*>(ty + (yrow + i * (256 / CY)) * PY + ychunk * 16) = ry[i];
 #pragma unroll
@@ -555,17 +611,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nkt = (kend - kbeg + BKP - 1) / BKP;
+    // one K' tile of register prefetch (a second register set was measured: it costs a wave of occupancy and
+    // runs 35 % slower -- three co-resident workgroups per CU hide the load latency better)
     uint4 ry[SY], rx[SX];
     if (nkt > 0) {
         load_tile(kbeg, ry, rx);
-        store_tile(0, ry, rx);
+        store_tile(ry, rx);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
         if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BKP, ry, rx);
-        const char* ty = smem + buf * BUF;
-        const char* tx = ty + BKP * PY;
 #pragma unroll
         for (int ks = 0; ks < BKP / WgFrag<T>::KSTEP; ++ks) {
             uint4 fa[2], fb[2];
@@ -578,7 +633,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
-        if (kt + 1 < nkt) store_tile(buf ^ 1, ry, rx);
+        __syncthreads();
+        if (kt + 1 < nkt) store_tile(ry, rx);
         __syncthreads();
     }
 
@@ -618,7 +674,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
 template <typename T, int WM, int WN>
 static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
     constexpr int PY = 64 * WM * (int)sizeof(T) + 64, PX = 64 * WN * (int)sizeof(T) + 64;
-    const int lds = 2 * 32 * (PY + PX);
+    const int lds = WgTile<T>::BKP * (PY + PX);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN>),
@@ -631,18 +687,18 @@ static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
     return 0;
 }
 
-static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int& wm, int& splits, int& klen) {
+static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen) {
     wm = N <= 64 ? 1 : 2;
     const int wn = 4 / wm;
     const int64_t tiles = ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
-    const int64_t nkt = (M + 31) / 32;
+    const int64_t nkt = (M + bkp - 1) / bkp;
     int64_t sp = 768 / tiles;     // ~3 workgroups per CU; every extra split costs an fp32 slab of the whole dW
     if (sp < 1) sp = 1;
     if (sp > nkt) sp = nkt;
     int64_t per = (nkt + sp - 1) / sp;        // K' tiles per split
     sp = (nkt + per - 1) / per;
     splits = (int)sp;
-    klen = (int)(per * 32);
+    klen = (int)(per * bkp);
 }
 
 }  // namespace mrfp
@@ -650,9 +706,10 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int& wm, int& splits, in
 extern "C" {
 
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q) {
-    int wm, splits, klen;
-    mrfp::wgrad_plan(M, N, Q, wm, splits, klen);
-    return (int64_t)splits * N * Q * 4;
+    int wm, s32, s64, klen;
+    mrfp::wgrad_plan(M, N, Q, 32, wm, s32, klen);         // fp32 K' tile
+    mrfp::wgrad_plan(M, N, Q, 64, wm, s64, klen);         // bf16 K' tile
+    return (int64_t)(s32 > s64 ? s32 : s64) * N * Q * 4;
 }
 
 int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype, int64_t B, int64_t H, int64_t W,
@@ -665,15 +722,19 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
     MRFP_CHECK((C * esz) % 16 == 0 && (ldn * esz) % 16 == 0 && ldn >= N && Ctrue <= C,
                "conv_wgrad: channel counts must make 16-byte chunks (C=%lld ldn=%lld)", (long long)C, (long long)ldn);
     MRFP_CHECK(aligned16(x) && aligned16(dy), "conv_wgrad: x / dy must be 16-byte aligned");
-    MRFP_CHECK(B * Ho * Wo < (1LL << 31) && B * H * W * C * esz < (1LL << 40), "conv_wgrad: tensor too large");
+    MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_wgrad: tensor too large");
     WgP p;
     p.x = (const char*)x; p.dy = (const char*)dy; p.slab = (float*)ws;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldn = (int)ldn;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil;
     p.M = (int)(B * Ho * Wo); p.Q = (int)(R * S * C);
+    const int64_t xb = B * H * W * C * esz, yb = (int64_t)p.M * ldn * esz;
+    MRFP_CHECK(xb < (int64_t)kOOB && yb < (int64_t)kOOB, "conv_wgrad: tensor exceeds the 3.75 GB buffer-descriptor range");
+    p.xbytes = (unsigned)xb; p.dybytes = (unsigned)yb;
+    p.div_hw = make_fastdiv((unsigned)(Ho * Wo)); p.div_w = make_fastdiv((unsigned)Wo);
     int wm, splits;
-    wgrad_plan(p.M, N, p.Q, wm, splits, p.klen);
+    wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st) : launch_wgrad<float, 2, 2>(p, splits, st);

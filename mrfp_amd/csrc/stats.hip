@@ -25,6 +25,7 @@ void set_error(const char* fmt, ...) {
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ fA, const float* __restrict__ fS,
                                                          int per_image, RowGeom g, int ly, float* __restrict__ ws) {
     __shared__ float sm[kThreads * 2 * VEC];
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
@@ -37,14 +38,21 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
     for (int cv0 = 0; cv0 < L.lpr; cv0 += kThreads) {
         const int cv = cv0 + tcol;
         const bool on = active && cv < L.lpr;
-        float s[VEC], q[VEC], mu[VEC];
+        float s[VEC], q[VEC], mu[VEC], fa[VEC], fs[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; mu[i] = 0.f; }
-        if (MODE == 1 && mean != nullptr && on) {
-            const float* mp = mean + (size_t)(per_image ? b : 0) * g.C + (size_t)cv * VEC;
+        for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; mu[i] = 0.f; fa[i] = 0.f; fs[i] = 1.f; }
+        if (MODE == 1 && on) {
+            const size_t co = (size_t)(per_image ? b : 0) * g.C + (size_t)cv * VEC;
+            if (mean != nullptr) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) mu[i] = mp[i];
+                for (int i = 0; i < VEC; ++i) mu[i] = mean[co + i];
+            }
+            if (fA != nullptr) {      // ReLU mask recomputed from x with the forward coefficients: (x*A + S) > 0
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { fa[i] = fA[co + i]; fs[i] = fS[co + i]; }
+            }
         }
+        const bool remask = MODE == 1 && y == nullptr && fA != nullptr;
         if (on) {
             for (int oh = j; oh < g.Ho; oh += ly) {
                 const int ih = g.tabH ? g.tabH[oh] : oh;
@@ -75,7 +83,9 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
                             } else {
 #pragma unroll
                                 for (int i = 0; i < VEC; ++i) {
-                                    const float d = (y != nullptr && !(yv[u][i] > 0.f)) ? 0.f : dv[u][i];
+                                    const bool dead = (y != nullptr && !(yv[u][i] > 0.f)) ||
+                                                      (remask && !(xv[u][i] * fa[i] + fs[i] > 0.f));
+                                    const float d = dead ? 0.f : dv[u][i];
                                     s[i] += d;
                                     q[i] += d * (xv[u][i] - mu[i]);
                                 }
@@ -107,7 +117,8 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
 }
 
 template <typename T, int MODE>
-static int launch_stats(const void* x, const void* dy, const void* y, const float* mean, int per_image,
+static int launch_stats(const void* x, const void* dy, const void* y, const float* mean, const float* fA,
+                        const float* fS, int per_image,
                         int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
                         const int32_t* tabH, const int32_t* tabW, float* ws, hipStream_t st) {
     RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, tabH, tabW};
@@ -116,10 +127,10 @@ static int launch_stats(const void* x, const void* dy, const void* y, const floa
     const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(x) && (MODE == 0 || (aligned16(dy) && (y == nullptr || aligned16(y))));
     if (vec_ok)
         hipLaunchKernelGGL((stats_kernel<T, FullVec<T>::value, MODE>), grid, dim3(kThreads), 0, st, (const T*)x,
-                           (const T*)dy, (const T*)y, mean, per_image, g, ly, ws);
+                           (const T*)dy, (const T*)y, mean, fA, fS, per_image, g, ly, ws);
     else
         hipLaunchKernelGGL((stats_kernel<T, 1, MODE>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)dy,
-                           (const T*)y, mean, per_image, g, ly, ws);
+                           (const T*)y, mean, fA, fS, per_image, g, ly, ws);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
@@ -409,18 +420,19 @@ int mrfp_stats_fwd(const void* x, int dtype, int64_t B, int64_t Ho, int64_t Wo, 
     MRFP_CHECK(x && ws && B > 0 && Ho > 0 && Wo > 0 && C > 0, "stats_fwd: bad arguments");
     MRFP_CHECK(C <= 65536 && B * Ho < (1LL << 31), "stats_fwd: shape out of range");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MRFP_F32) return launch_stats<float, 0>(x, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
-    if (dtype == MRFP_BF16) return launch_stats<bf16, 0>(x, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_F32) return launch_stats<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_BF16) return launch_stats<bf16, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     MRFP_CHECK(false, "stats_fwd: unknown dtype %d", dtype);
 }
 
-int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* mean, int per_image, int dtype,
+int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* fA, const float* fS,
+                   int per_image, int dtype,
                    int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws, const int32_t* tabH,
                    const int32_t* tabW, float* ws, void* stream) {
     MRFP_CHECK(dy && x && ws && B > 0 && Ho > 0 && Wo > 0 && C > 0, "stats_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MRFP_F32) return launch_stats<float, 1>(x, dy, y, mean, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
-    if (dtype == MRFP_BF16) return launch_stats<bf16, 1>(x, dy, y, mean, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_F32) return launch_stats<float, 1>(x, dy, y, mean, fA, fS, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_BF16) return launch_stats<bf16, 1>(x, dy, y, mean, fA, fS, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     MRFP_CHECK(false, "stats_bwd: unknown dtype %d", dtype);
 }
 

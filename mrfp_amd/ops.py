@@ -126,11 +126,11 @@ def _stats_fwd(x, plan):
     return nslab, ws
 
 
-def _stats_bwd(dy, x, y, mean, per_image, plan):
+def _stats_bwd(dy, x, y, mean, per_image, plan, fA=None, fS=None):
     B, Ho, Wo, C, Hs, Ws, tH, tW, _, _ = _geom(x, plan)
     nslab, ws = _stats_ws(B, Ho, C, x.device)
-    call("mrfp_stats_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), int(per_image), dt(x), B, Ho, Wo, C, Hs, Ws,
-         ptr(tH), ptr(tW), ptr(ws), stream())
+    call("mrfp_stats_bwd", ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(fA), ptr(fS), int(per_image), dt(x), B, Ho, Wo, C,
+         Hs, Ws, ptr(tH), ptr(tW), ptr(ws), stream())
     return nslab, ws
 
 
@@ -143,12 +143,12 @@ def _affine_fwd(x, res, A, S, per_image, relu, plan, like=None):
     return y
 
 
-def _affine_bwd(dy, x, y, P, Q, R, per_image, plan, want_dres, like):
+def _affine_bwd(dy, x, y, P, Q, R, per_image, plan, want_dres, like, fA=None, fS=None):
     B, Ho, Wo, C, Hs, Ws, _, _, iH, iW = _geom(like, plan)
     dx = empty_cl(B, C, Hs, Ws, dy.dtype, dy.device)
     dres = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device) if want_dres else None
     call("mrfp_affine_bwd", ptr(dy), ptr(x), ptr(y), ptr(dx), ptr(dres), dt(dy), B, Ho, Wo, C, Hs, Ws,
-         ptr(iH), ptr(iW), ptr(P), ptr(Q), ptr(R), int(per_image), stream())
+         ptr(iH), ptr(iW), ptr(P), ptr(Q), ptr(R), ptr(fA), ptr(fS), int(per_image), stream())
     return dx, dres
 
 
@@ -177,23 +177,29 @@ class _BatchNormAct(torch.autograd.Function):
                  ptr(A), ptr(S), stream())
         y = _affine_fwd(x, res, A, S, False, relu, plan)
         ctx.plan, ctx.relu, ctx.training, ctx.has_res = plan, relu, training, res is not None
-        ctx.save_for_backward(x, y if relu else None, w32, mean, invstd)
+        # ReLU mask for backward: without a residual it is recomputed from x and the apply coefficients
+        # ((x*A+S) > 0, bit-identical to the forward expression), so y is not read again; with a residual the
+        # stored output is the only place the sign lives.
+        keep_y = relu and res is not None
+        ctx.remask = relu and res is None
+        ctx.save_for_backward(x, y if keep_y else None, w32, mean, invstd, A, S)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, w32, mean, invstd = ctx.saved_tensors
+        x, y, w32, mean, invstd, A, S = ctx.saved_tensors
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the MRFP hot path")
         dy = _chk(dy, "dy")
         plan = ctx.plan
         B, Ho, Wo, C, *_ = _geom(x, plan)
-        nslab, ws = _stats_bwd(dy, x, y, mean, False, plan)
+        fA, fS = (A, S) if ctx.remask else (None, None)
+        nslab, ws = _stats_bwd(dy, x, y, mean, False, plan, fA, fS)
         out = torch.empty(5 * C, dtype=torch.float32, device=dy.device)
         dw, db, P, Q, R = (out[i * C:(i + 1) * C] for i in range(5))
         call("mrfp_bn_bwd_finalize", ptr(ws), B, nslab, B * Ho * Wo, C, ptr(w32), ptr(mean), ptr(invstd),
              ptr(dw), ptr(db), ptr(P), ptr(Q), ptr(R), stream())
-        dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x)
+        dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x, fA, fS)
         return dx, dw, db, None, None, dres, None, None, None, None, None
 
 
@@ -221,22 +227,23 @@ class _InstanceNormAct(torch.autograd.Function):
              ptr(invstd), ptr(A), ptr(S), stream())
         y = _affine_fwd(x, None, A, S, True, relu, None)
         ctx.relu, ctx.affine = relu, weight is not None
-        ctx.save_for_backward(x, y if relu else None, w32, mean, invstd)
+        ctx.save_for_backward(x, w32, mean, invstd, A, S)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, w32, mean, invstd = ctx.saved_tensors
+        x, w32, mean, invstd, A, S = ctx.saved_tensors
         dy = _chk(dy, "dy")
         B, C, H, W = x.shape
-        nslab, ws = _stats_bwd(dy, x, y, mean, True, None)
+        fA, fS = (A, S) if ctx.relu else (None, None)      # ReLU mask recomputed from x (see _BatchNormAct)
+        nslab, ws = _stats_bwd(dy, x, None, mean, True, None, fA, fS)
         pqr = torch.empty(3 * B * C, dtype=torch.float32, device=dy.device)
         n = B * C
         P, Q, R = pqr[0:n], pqr[n:2 * n], pqr[2 * n:3 * n]
         dwb = torch.empty(2 * C, dtype=torch.float32, device=dy.device)
         call("mrfp_in_bwd_finalize", ptr(ws), B, nslab, H * W, C, ptr(w32), ptr(mean), ptr(invstd),
              ptr(dwb[:C]), ptr(dwb[C:]), ptr(P), ptr(Q), ptr(R), stream())
-        dx, _ = _affine_bwd(dy, x, y, P, Q, R, True, None, False, x)
+        dx, _ = _affine_bwd(dy, x, None, P, Q, R, True, None, False, x, fA, fS)
         if ctx.affine:
             return dx, dwb[:C], dwb[C:], None, None
         return dx, None, None, None, None
