@@ -527,3 +527,100 @@ def concat_channels(tensors):
     """torch.cat(dim=1) of NHWC activations (reference deepv3.py:125, 353).  A strided copy: pure
     data movement by the allocator-side runtime, no arithmetic."""
     return torch.cat([_chk(t) for t in tensors], 1).contiguous(memory_format=CL)
+
+
+# ------------------------------------------------------------------------------------------
+# second-moment statistics for the whitening options (iw = 1, 2, 5)
+# ------------------------------------------------------------------------------------------
+class _PlaneMean(torch.autograd.Function):
+    """mean over H*W per (b, c) in fp32 -- in_data.mean(-1) of reference sync_switchwhiten.py:20, 161."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        B, C, H, W = x.shape
+        nslab, ws = _stats_fwd(x, None)
+        out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        call("mrfp_mean_finalize", ptr(ws), B, nslab, H * W, C, ptr(out), ptr(out), _lib.F32, stream())
+        ctx.dims, ctx.dtype = (B, C, H, W), x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.dims
+        S = (g.detach().float() / float(H * W)).contiguous()
+        dx = empty_cl(B, C, H, W, ctx.dtype, g.device)
+        call("mrfp_affine_fwd", None, None, ptr(dx), _lib._DT[ctx.dtype], B, H, W, C, H, W, None, None, None, ptr(S), 1, 0,
+             stream())
+        return dx
+
+
+def plane_mean(x):
+    return _PlaneMean.apply(x)
+
+
+class _CrossGram(torch.autograd.Function):
+    """G[b] = sum over pixels of a[b,:,p] b[b,:,p]^T  ([B,Ca,Cb], fp32): the bmm(f, f^T) of reference
+    instance_whitening.py:36 and sync_switchwhiten.py:23, 165.  Runs on the MFMA weight-gradient kernel
+    (the same "reduce over pixels" GEMM), its backward on the 1x1 implicit-GEMM kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "a"), _chk(b, "b")
+        B, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        esz = a.element_size()
+        if (Ca * esz) % 16 or (Cb * esz) % 16 or a.dtype != b.dtype or b.shape[0] != B or b.shape[2:] != a.shape[2:]:
+            raise _lib.MrfpHipError("cross_gram: channel counts must make 16-byte chunks and shapes must match")
+        G = torch.empty(B, Ca, Cb, dtype=torch.float32, device=a.device)
+        ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(H * W, Ca, Cb)), dtype=torch.uint8, device=a.device)
+        abytes, bbytes = H * W * Ca * esz, H * W * Cb * esz
+        for i in range(B):
+            call("mrfp_conv_wgrad", b.data_ptr() + i * bbytes, a.data_ptr() + i * abytes, G.data_ptr() + i * Ca * Cb * 4,
+                 ptr(ws), dt(a), 1, H, W, Cb, Cb, Ca, Ca, 1, 1, H, W, 1, 0, 0, 1, stream())
+        ctx.save_for_backward(a, b)
+        ctx.same = a.data_ptr() == b.data_ptr()
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        from . import conv
+        a, b = ctx.saved_tensors
+        B = a.shape[0]
+        dG = dG.float()
+        da = db = None
+        if ctx.same:          # d(x x^T): x (dG + dG^T), returned once (both inputs are the same tensor)
+            sym = dG + dG.transpose(1, 2)
+            parts = [conv.conv2d(a[i:i + 1].detach(), sym[i].reshape(*sym.shape[1:], 1, 1).contiguous(), None, 1, 0, 1)
+                     for i in range(B)]
+            return torch.cat(parts, 0), None
+        if ctx.needs_input_grad[0]:
+            da = torch.cat([conv.conv2d(b[i:i + 1].detach(), dG[i].reshape(*dG.shape[1:], 1, 1).contiguous(), None, 1, 0, 1)
+                            for i in range(B)], 0)
+        if ctx.needs_input_grad[1]:
+            dGt = dG.transpose(1, 2).contiguous()
+            db = torch.cat([conv.conv2d(a[i:i + 1].detach(), dGt[i].reshape(*dGt.shape[1:], 1, 1).contiguous(), None, 1, 0, 1)
+                            for i in range(B)], 0)
+        return da, db
+
+
+def cross_gram(a, b):
+    return _CrossGram.apply(a, b)
+
+
+def channel_gram(x):
+    """sum over pixels of x x^T per image: [B,C,C] fp32 (divide by HW-1 / HW for a covariance)."""
+    x = _chk(x)
+    return _CrossGram.apply(x, x)
+
+
+def per_image_matmul(x, Wm, bias=None):
+    """y[b,:,p] = Wm[b] @ x[b,:,p] (+ bias[b]): torch.bmm(wm, in_data) of reference sync_switchwhiten.py:217 as one
+    1x1 implicit-GEMM convolution per image (weights differ per image); autograd flows into Wm and bias."""
+    from . import conv
+    x = _chk(x)
+    outs = []
+    for i in range(x.shape[0]):
+        w = Wm[i].reshape(Wm.shape[1], Wm.shape[2], 1, 1)
+        outs.append(conv.conv2d(x[i:i + 1], w, None if bias is None else bias[i], 1, 0, 1))
+    return torch.cat(outs, 0)
