@@ -208,6 +208,21 @@ int mrfp_nchw_to_nhwc_pad(const float* x, void* y, int dtype, int64_t B, int64_t
 int mrfp_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum,
                   float weight_decay, float gscale, int first, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fourier amplitude perturbation (north_star extension; no function of this kind exists in the
+ * reference's model -- nearest arithmetic: dataloaders.py:24-79; semantics are build-defined):
+ *   F = rfft2(x[b,:,:,c]); ratio = band ? ((1-lam)|F| + lam|F_partner|)/|F| : 1; y = irfft2(F*ratio)
+ *   band = (min(kh,H-kh)^2 + kw^2 <= radius^2), complemented when high != 0; partner = perm[b].
+ * S, S3: scratch spectra of mrfp_fourier_spectrum_bytes() bytes each; ratio (optional, float
+ * [B,H,W/2+1,C]) is written (load_ratio = 0) or read (load_ratio = 1: the backward pass applies the same
+ * detached ratio to the gradient).  twH / twW: float2 tables exp(-2 pi i t/N), t < N, for N = H and N = W.
+ * H, W of the form 2^a 3^b, <= 512, W even; C % 16 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int64_t mrfp_fourier_spectrum_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
+int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void* S3, float* ratio, int load_ratio,
+                     const void* twH, const void* twW, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
+                     float radius, float lam, int high, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

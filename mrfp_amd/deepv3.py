@@ -210,6 +210,7 @@ class MRFPPlus(_DeepLabBase):
             initialize_weights_kaimingnormal_forOC(bn)
         self._init_head()
         self.rng = ReferenceRandom()
+        self.fourier_perturb = None      # optional build-defined extension (mrfp_amd/perturb.py); off = reference path
 
     def hrfp_layers(self):
         """(conv, bn) pairs in the reference's re-initialisation order (deepv3.py:291-306)."""
@@ -247,6 +248,8 @@ class MRFPPlus(_DeepLabBase):
             self.rng.reinit_hrfp(self)
 
         xp, w_arr = self._stem(x)
+        if training == True and self.fourier_perturb is not None:      # noqa: E712  (extension, default off)
+            xp = self.fourier_perturb(xp)
         t = xp
         if npp:
             t = self.Normalization_Perturbation_Plus(xp, "np1")

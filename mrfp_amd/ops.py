@@ -624,3 +624,57 @@ def per_image_matmul(x, Wm, bias=None):
         w = Wm[i].reshape(Wm.shape[1], Wm.shape[2], 1, 1)
         outs.append(conv.conv2d(x[i:i + 1], w, None if bias is None else bias[i], 1, 0, 1))
     return torch.cat(outs, 0)
+
+
+# ------------------------------------------------------------------------------------------
+# Fourier amplitude perturbation (build-defined extension)
+# ------------------------------------------------------------------------------------------
+@lru_cache(maxsize=32)
+def _twiddles(n: int, device_str: str) -> torch.Tensor:
+    t = np.arange(n, dtype=np.float64)
+    tab = np.stack([np.cos(2 * np.pi * t / n), -np.sin(2 * np.pi * t / n)], 1).astype(np.float32)
+    return torch.from_numpy(tab).to(device_str)
+
+
+class _FourierMix(torch.autograd.Function):
+    """y = irfft2(rfft2(x) * ratio), ratio = band ? ((1-lam)|F| + lam|F[perm]|)/|F| : 1 (detached).
+    The backward applies the same (saved) ratio to the gradient: the operator is real-symmetric."""
+
+    @staticmethod
+    def forward(ctx, x, perm, radius, lam, high):
+        x = _chk(x)
+        B, C, H, W = x.shape
+        dev = x.device
+        nbytes = int(_lib.lib().mrfp_fourier_spectrum_bytes(B, H, W, C))
+        S = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        S3 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ratio = torch.empty(B * H * (W // 2 + 1) * C, dtype=torch.float32, device=dev)
+        y = empty_cl(B, C, H, W, x.dtype, dev)
+        perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+        twH, twW = _twiddles(H, str(dev)), _twiddles(W, str(dev))
+        call("mrfp_fourier_mix", ptr(x), ptr(y), ptr(perm), ptr(S), ptr(S3), ptr(ratio), 0, ptr(twH), ptr(twW), dt(x),
+             B, H, W, C, float(radius), float(lam), int(bool(high)), stream())
+        ctx.save_for_backward(ratio)
+        ctx.dims = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ratio,) = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        B, C, H, W = ctx.dims
+        dev = dy.device
+        nbytes = int(_lib.lib().mrfp_fourier_spectrum_bytes(B, H, W, C))
+        S = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        S3 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dx = empty_cl(B, C, H, W, dy.dtype, dev)
+        twH, twW = _twiddles(H, str(dev)), _twiddles(W, str(dev))
+        call("mrfp_fourier_mix", ptr(dy), ptr(dx), None, ptr(S), ptr(S3), ptr(ratio), 1, ptr(twH), ptr(twW), dt(dy),
+             B, H, W, C, 0.0, 0.0, 0, stream())
+        return dx, None, None, None, None
+
+
+def fourier_amplitude_mix(x, perm, radius, lam=1.0, high=False):
+    """Per-(b,c) plane: swap/blend the spectral amplitude inside (low band) or outside (high band) `radius`
+    with the partner sample perm[b], keep the phase."""
+    return _FourierMix.apply(x, perm, radius, lam, high)

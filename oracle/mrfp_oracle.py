@@ -364,3 +364,23 @@ def eval_hist(sd, x: Tensor, y: Tensor) -> np.ndarray:
         logits = mrfp_forward(sd, x, training=False, bn_train=False)
     pred = logits.numpy().argmax(1)
     return fast_hist(pred.flatten(), y.numpy().astype("int64").flatten(), logits.shape[1])
+
+
+# --------------------------------------------------------------------------------------
+# Fourier amplitude perturbation -- BUILD-DEFINED (parity unpinned: the reference model has no such
+# function; nearest reference arithmetic: dataloaders.py:24-79 HPF/LPF radial masks, PHOT phase-only)
+# --------------------------------------------------------------------------------------
+def fourier_amplitude_mix(x: Tensor, perm: Tensor, radius: float, lam: float = 1.0, high: bool = False) -> Tensor:
+    """y = irfft2(F * ratio) per (b, c) plane, F = rfft2(x); inside the selected band the amplitude becomes
+    (1-lam)|F| + lam|F[perm]| with the phase of F; ratio is detached (no gradient through the amplitudes)."""
+    B, C, H, W = x.shape
+    F_ = torch.fft.rfft2(x.float())
+    A = F_.abs()
+    Ap = A[perm]
+    kh = torch.arange(H)
+    dh = torch.minimum(kh, H - kh).float()
+    kw = torch.arange(W // 2 + 1).float()
+    band = (dh[:, None] ** 2 + kw[None, :] ** 2) <= float(radius) ** 2
+    sel = (~band if high else band)[None, None]
+    ratio = torch.where(sel & (A > 1e-20), ((1 - lam) * A + lam * Ap) / A.clamp_min(1e-30), torch.ones_like(A)).detach()
+    return torch.fft.irfft2(F_ * ratio, s=(H, W))

@@ -1,0 +1,52 @@
+"""Fourier amplitude perturbation (north_star extension; PARITY UNPINNED: no reference function
+exists) -- HIP kernels against the CPU oracle built on torch.fft, forward and backward."""
+import pytest
+import torch
+
+from oracle import mrfp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,radius,lam,high", [((2, 16, 8, 8), 2.0, 1.0, False), ((3, 32, 48, 64), 6.0, 1.0, False),
+                                                   ((2, 64, 64, 64), 16.0, 0.5, True), ((2, 16, 96, 192), 16.0, 1.0, False),
+                                                   ((4, 16, 12, 18), 3.0, 0.7, True)])
+def test_fourier_amplitude_mix(dtype, shape, radius, lam, high):
+    from mrfp_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(*shape, generator=g) + 0.3
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    perm = torch.randperm(B, generator=g)
+    xc = x.clone().requires_grad_(True)
+    yc = orc.fourier_amplitude_mix(xc, perm, radius, lam, high)
+    gy = torch.randn(yc.shape, generator=g)
+    yc.backward(gy)
+    xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yd = ops.fourier_amplitude_mix(xd, perm, radius, lam, high)
+    yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert relerr(yd, yc) < tol
+    assert relerr(xd.grad, xc.grad) < tol
+
+
+def test_identity_when_partner_is_self():
+    from mrfp_amd import ops
+    x = torch.randn(2, 16, 24, 32).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = ops.fourier_amplitude_mix(x, torch.arange(2), 8.0, 1.0, False)
+    assert relerr(y, x) < 1e-5
+
+
+def test_unsupported_length_fails_loudly():
+    from mrfp_amd import _lib, ops
+    x = torch.randn(1, 16, 10, 14).to(DEV).contiguous(memory_format=torch.channels_last)   # 14 = 2*7
+    with pytest.raises(_lib.MrfpHipError):
+        ops.fourier_amplitude_mix(x, torch.arange(1), 2.0)
