@@ -187,3 +187,27 @@ def evaluate(model, batches, num_classes=19):
         dist.all_reduce(hist)
     h = hist.cpu().numpy() if hist is not None else None
     return h, (metrics.miou_from_hist(h) if h is not None else 0.0), dropped
+
+
+# ------------------------------------------------------------------------------------------
+# checkpoints in the reference's format (reference main.py:867-869, 884-886)
+# ------------------------------------------------------------------------------------------
+def save_checkpoint(path, model, epoch, optimizer_state=None):
+    """{'epoch', 'state_dict', ['optimizer']} with the `module.` prefix nn.DataParallel gives the keys."""
+    sd = {"module." + k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ck = {"epoch": epoch, "state_dict": sd}
+    if optimizer_state is not None:
+        ck["optimizer"] = optimizer_state
+    torch.save(ck, path)
+
+
+def load_checkpoint(path_or_dict, model, strict=True):
+    """Loads a reference checkpoint (keys with or without the `module.` prefix) into the HIP model."""
+    ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, str) else path_or_dict
+    sd = ck["state_dict"] if "state_dict" in ck else ck
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    with torch.no_grad():
+        missing = model.load_state_dict(sd, strict=strict)
+    from . import conv
+    conv.invalidate_packs()
+    return ck.get("epoch", None) if isinstance(ck, dict) else None, missing

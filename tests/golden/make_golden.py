@@ -249,6 +249,13 @@ def main():
         for k in GRAD_KEYS:
             assert rel(sd_o[k], ref_sd[k]) < 1e-5, (k, rel(sd_o[k], ref_sd[k]))
         out[f"{tag}_losses"] = np.array(losses_ref, dtype=np.float64)
+        # the same three iterations evaluated in fp64: how far the reference's fp32 trajectory is from the
+        # exact one (conditioning), so that tests can hold other fp32 implementations to the same band
+        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        b64 = [(bx.double(), by) for bx, by in batches]
+        n64 = [{k: v.double() for k, v in nz.items()} for nz in noises]
+        out[f"{tag}_losses64"] = np.array(orc.train_steps(sd64, b64, toggles_seq, n64, lr=lr), dtype=np.float64)
+        print(f"      fp64 trajectory {out[f'{tag}_losses64']}")
         for k in GRAD_KEYS:
             out[f"{tag}_param_head/{k}"] = ref_sd[k].flatten()[:8].numpy()
             out[f"{tag}_param_delta_l2/{k}"] = np.float64((ref_sd[k] - sd0[k]).double().pow(2).sum().sqrt().item())

@@ -1,0 +1,147 @@
+"""Train-step and eval harness against numbers captured from the reference's
+optimiser loop (torch.optim.SGD + LambdaLR poly 0.9 on the reference module, tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mrfp_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "mrfp_c1.npz"))
+SPEC = json.load(open(os.path.join(HERE, "golden", "state_dict_spec.json")))
+
+
+def _model():
+    from mrfp_amd import deepv3
+    from mrfp_amd.config import cfg
+    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.float32
+    m = deepv3.MRFPPlus(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
+    sd = synth.synth_state_dict([(k, tuple(s)) for k, s in SPEC["MRFPPlus"]], seed=0)
+    m.load_state_dict(sd)
+    return m.to(DEV), sd
+
+
+def _check_trajectory(losses, tag):
+    """Each loss must be as close to the fp64 evaluation of the reference's loop as the reference's own fp32 run is
+    (x3 slack, + 1e-3 relative floor).  Measured (make_golden.py): at lr 1e-4 the reference's third fp32 loss is
+    2.6e-3 off the fp64 one, at lr 1e-2 the trajectory is chaotic (a 1-ulp change of the update moves it 3e-3)."""
+    ref32, ref64 = G[f"{tag}_losses"], G[f"{tag}_losses64"]
+    for i, l in enumerate(losses):
+        band = 3 * abs(ref32[i] - ref64[i]) + 1e-3 * abs(ref64[i])
+        assert abs(l - ref64[i]) <= band, (tag, i, l, ref32[i], ref64[i])
+    assert abs(losses[0] - ref32[0]) / ref32[0] < 1e-4      # the first step has no accumulated history
+
+
+def test_three_train_steps_low_lr_match_reference_sgd():
+    """lr 1e-4 (the well-conditioned pin, see make_golden.py): losses and parameter heads after 3 iterations of
+    zero_grad -> backward -> fused SGD(momentum .9, wd 5e-4) -> poly LR."""
+    from mrfp_amd.deepv3 import InjectedRandom
+    from mrfp_amd.harness import Trainer
+    model, sd0 = _model()
+    model.train()
+    tr = Trainer(model, lr=1e-4)
+    toggles = [(True, True, True), (False, True, False), (True, False, True)]
+    losses = []
+    for i in range(3):
+        x, y = synth.synth_batch(2, 256, 256, seed=10 + i)
+        model.rng = InjectedRandom(toggles[i], synth.synth_noise(2, seed=20 + i))
+        losses.append(tr.step(x.to(DEV), y.to(DEV)).item())
+    _check_trajectory(losses, "train3lo")
+    msd = model.state_dict()
+    # parameter updates: checked element-wise on the well-conditioned head of the network (the stem-side updates
+    # inherit the 2.5e-2 gradient noise of fp32 and then feed a chaotic trajectory; the optimiser arithmetic itself
+    # is pinned exactly by test_fused_sgd_matches_torch_optim below)
+    for k in ("final2.0.weight", "final2.0.bias", "final1.4.weight"):
+        ref_head = G[f"train3lo_param_head/{k}"]
+        delta = float(G[f"train3lo_param_delta_l2/{k}"])
+        got = msd[k].flatten()[:8].cpu().numpy()
+        # the update itself (not just the parameter) must agree: compare the deltas against the tensor's delta RMS
+        d_got, d_ref = got - sd0[k].flatten()[:8].numpy(), ref_head - sd0[k].flatten()[:8].numpy()
+        rms = delta / np.sqrt(msd[k].numel())
+        np.testing.assert_allclose(d_got, d_ref, rtol=0.05, atol=0.15 * rms + 1e-9, err_msg=k)
+    assert int(msd["layer1.0.bn1.num_batches_tracked"]) == int(G["train3lo_nbt"])
+    assert tr.opt.it == 3 and abs(tr.opt.lr - 1e-4 * (1 - 3 / 40000) ** 0.9) < 1e-12
+
+
+def test_fused_sgd_matches_torch_optim():
+    """mrfp_sgd_step over the flat arena == torch.optim.SGD(momentum .9, wd 5e-4) + LambdaLR(poly .9), 3 steps."""
+    from mrfp_amd.harness import FlatSGD
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5))
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5))
+    ref.load_state_dict(net.state_dict())
+    net = net.to(DEV)
+    opt = FlatSGD(net, lr=1e-2, max_iter=10)
+    ropt = torch.optim.SGD(ref.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(ropt, lr_lambda=lambda it: (1 - it / 10) ** 0.9)
+    for step in range(3):
+        x = torch.randn(11, 37)
+        opt.zero_grad()
+        net(x.to(DEV)).pow(2).sum().backward()
+        opt.step(gscale=1.0)
+        ropt.zero_grad()
+        ref(x).pow(2).sum().backward()
+        ropt.step()
+        sched.step()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=2e-5, atol=1e-6)
+    # gscale folds the data-parallel 1/world averaging into the update
+    opt.zero_grad()
+    net(torch.ones(3, 37, device=DEV)).sum().backward()
+    before = opt.flat_p.clone()
+    g = opt.flat_g.clone()
+    m = opt.flat_m.clone()
+    lr = opt.lr
+    opt.step(gscale=0.25)
+    exp_m = 0.9 * m + (0.25 * g + 5e-4 * before)
+    torch.testing.assert_close(opt.flat_p, before - lr * exp_m, rtol=1e-5, atol=1e-7)
+
+
+def test_reference_recipe_lr_runs_and_tracks_reference():
+    """lr 1e-2 (the reference's recipe): the trajectory is chaotic with synthetic weights (a 1-ulp change of the
+    update moves loss 3 by 3e-3, measured in make_golden.py) -> loose, stated tolerance 2e-2."""
+    from mrfp_amd.deepv3 import InjectedRandom
+    from mrfp_amd.harness import Trainer
+    model, _ = _model()
+    model.train()
+    tr = Trainer(model, lr=1e-2)
+    toggles = [(True, True, True), (False, True, False), (True, False, True)]
+    losses = []
+    for i in range(3):
+        x, y = synth.synth_batch(2, 256, 256, seed=10 + i)
+        model.rng = InjectedRandom(toggles[i], synth.synth_noise(2, seed=20 + i))
+        losses.append(tr.step(x.to(DEV), y.to(DEV)).item())
+    _check_trajectory(losses, "train3")
+
+
+def test_eval_harness_hist_miou_and_checkpoint_roundtrip(tmp_path):
+    from mrfp_amd import harness
+    model, sd = _model()
+    x, y = synth.synth_batch(2, 256, 256, seed=1)
+    # one image per eval iteration like the reference loop (bs 1), one with a mismatching label size (dropped)
+    batches = [(x[i:i + 1].to(DEV), y[i:i + 1].to(DEV)) for i in range(2)]
+    batches.append((x[:1].to(DEV), y[:1, :128].to(DEV)))
+    hist, miou, dropped = harness.evaluate(model, batches)
+    assert dropped == 1
+    assert np.abs(hist - G["eval_hist"]).sum() <= 0.002 * hist.sum()
+    assert abs(100 * miou - 100 * float(G["eval_miou"])) < 0.1
+    path = str(tmp_path / "ck.pth")
+    harness.save_checkpoint(path, model, epoch=3)
+    ck = torch.load(path)
+    assert set(ck) == {"epoch", "state_dict"} and all(k.startswith("module.") for k in ck["state_dict"])
+    assert len(ck["state_dict"]) == 431
+    from mrfp_amd import deepv3
+    m2 = deepv3.MRFPPlus(19).to(DEV)
+    epoch, _ = harness.load_checkpoint(path, m2)
+    assert epoch == 3
+    with torch.no_grad():
+        m2.eval()
+        l1 = m2(x.to(DEV), training=False)
+        model.eval()
+        l0 = model(x.to(DEV), training=False)
+    assert torch.equal(l0, l1)
