@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import CL, _chk, empty_cl, zeros_cl
+from .ops import CL, _chk, empty_cl, grad_sink, notify_grad, zeros_cl
 
 _PACKS = {}      # id(weight Parameter) -> {key: _Pack}; entry dropped when the Parameter dies
 _EPOCH = [0]     # bumped by writers that bypass autograd's version counters (the fused SGD kernel)
@@ -104,10 +104,14 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             M, Q = B * Ho * Wo, R * S * Cphys
             ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
-            dw = torch.empty((N, C, R, S), dtype=torch.float32, device=x.device)
+            sink = grad_sink(weight)      # the parameter's slot in the flat gradient arena, when the harness owns it
+            dw = sink if sink is not None else torch.empty((N, C, R, S), dtype=torch.float32, device=x.device)
             call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), dt(x), B, H, W, Cphys, C, N, Nphys, R, S, Ho, Wo,
                  stride, pad_h, pad_w, dil, stream())
-            if dw.dtype != weight.dtype:
+            if sink is not None:
+                notify_grad(weight)
+                dw = None
+            elif dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
             from .ops import _stats_fwd

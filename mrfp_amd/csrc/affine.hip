@@ -31,28 +31,43 @@ __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restric
             const int ih = g.tabH ? g.tabH[oh] : oh;
             const T* xl = x ? x + ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC : nullptr;
             const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
-            for (int ow = trow; ow < g.Wo; ow += L.rowthreads) {
-                const int iw = g.tabW ? g.tabW[ow] : ow;
-                float v[VEC];
-                if (xl) {
-                    load_f<T, VEC>(xl + (size_t)iw * g.C, v);
+            // 4 independent pixels per trip (up to 8 16-byte loads in flight per lane)
+            for (int ow0 = trow; ow0 < g.Wo; ow0 += 4 * L.rowthreads) {
+                VecT<T, VEC> xr[4], rr[4];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[i] = v[i] * a[i] + s[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[i] = s[i];
+                for (int u = 0; u < 4; ++u) {
+                    const int ow = ow0 + u * L.rowthreads;
+                    if (ow < g.Wo) {
+                        const int iw = g.tabW ? g.tabW[ow] : ow;
+                        if (xl) xr[u] = load_raw<T, VEC>(xl + (size_t)iw * g.C);
+                        if (res) rr[u] = load_raw<T, VEC>(res + dl + (size_t)ow * g.C);
+                    }
                 }
-                if (res) {
-                    float r[VEC];
-                    load_f<T, VEC>(res + dl + (size_t)ow * g.C, r);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[i] += r[i];
-                }
-                if (relu) {
+                for (int u = 0; u < 4; ++u) {
+                    const int ow = ow0 + u * L.rowthreads;
+                    if (ow >= g.Wo) continue;
+                    float v[VEC];
+                    if (xl) {
+                        cvt_f<T, VEC>(xr[u], v);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                        for (int i = 0; i < VEC; ++i) v[i] = v[i] * a[i] + s[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[i] = s[i];
+                    }
+                    if (res) {
+                        float r[VEC];
+                        cvt_f<T, VEC>(rr[u], r);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[i] += r[i];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                    }
+                    store_f<T, VEC>(y + dl + (size_t)ow * g.C, v);
                 }
-                store_f<T, VEC>(y + dl + (size_t)ow * g.C, v);
             }
         }
     }
@@ -88,6 +103,48 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
         if (remask) {
             load_coef<VEC>(fA + cbase + (size_t)cv * VEC, fa);
             load_coef<VEC>(fS + cbase + (size_t)cv * VEC, fs);
+        }
+        if (!invH && !invW) {
+            // identity geometry (every BN / IN / NP+ outside the HRFP branch): 4 pixels per trip, loads first
+            for (int ih = j; ih < g.Hs; ih += ly) {
+                const size_t sl = ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
+                for (int iw0 = trow; iw0 < g.Ws; iw0 += 4 * L.rowthreads) {
+                    VecT<T, VEC> dr[4], xr[4], yr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int iw = iw0 + u * L.rowthreads;
+                        if (iw < g.Ws) {
+                            dr[u] = load_raw<T, VEC>(dy + sl + (size_t)iw * g.C);
+                            if (x && (Q || remask)) xr[u] = load_raw<T, VEC>(x + sl + (size_t)iw * g.C);
+                            if (y) yr[u] = load_raw<T, VEC>(y + sl + (size_t)iw * g.C);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int iw = iw0 + u * L.rowthreads;
+                        if (iw >= g.Ws) continue;
+                        float dv[VEC], xv[VEC], o[VEC];
+                        cvt_f<T, VEC>(dr[u], dv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) xv[i] = 0.f;
+                        if (x && (Q || remask)) cvt_f<T, VEC>(xr[u], xv);
+                        if (y) {
+                            float yv[VEC];
+                            cvt_f<T, VEC>(yr[u], yv);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) dv[i] = yv[i] > 0.f ? dv[i] : 0.f;
+                        } else if (remask) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) dv[i] = (xv[i] * fa[i] + fs[i] > 0.f) ? dv[i] : 0.f;
+                        }
+                        if (dres) store_f<T, VEC>(dres + sl + (size_t)iw * g.C, dv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) o[i] = p[i] * dv[i] + (q[i] * xv[i] + r[i]);
+                        store_f<T, VEC>(dx + sl + (size_t)iw * g.C, o);
+                    }
+                }
+            }
+            continue;
         }
         for (int ih = j; ih < g.Hs; ih += ly) {
             const int oh0 = invH ? invH[2 * ih] : ih, oh1 = invH ? invH[2 * ih + 1] : ih + 1;

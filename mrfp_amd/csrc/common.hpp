@@ -58,6 +58,15 @@ __device__ __forceinline__ void store_f(T* p, const float (&in)[VEC]) {
     for (int i = 0; i < VEC; ++i) t.v[i] = from_f<T>(in[i]);
     *reinterpret_cast<VecT<T, VEC>*>(p) = t;
 }
+// raw (unconverted) vector loads: keep several 16-byte loads in flight per lane at 4 VGPRs each, convert on use
+template <typename T, int VEC>
+__device__ __forceinline__ VecT<T, VEC> load_raw(const T* p) { return *reinterpret_cast<const VecT<T, VEC>*>(p); }
+template <typename T, int VEC>
+__device__ __forceinline__ void cvt_f(const VecT<T, VEC>& t, float (&out)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = to_f(t.v[i]);
+}
+
 template <int VEC>
 __device__ __forceinline__ void load_coef(const float* p, float (&out)[VEC]) {
     VecT<float, VEC> t = *reinterpret_cast<const VecT<float, VEC>*>(p);

@@ -60,16 +60,16 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
                 const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
                 // 4 independent pixels per trip: 4 (MODE 0) or up to 12 (MODE 1) 16-byte loads in flight per lane
                 for (int ow0 = trow; ow0 < g.Wo; ow0 += 4 * L.rowthreads) {
-                    float xv[4][VEC], dv[4][VEC], yv[4][VEC];
+                    VecT<T, VEC> xr[4], dr[4], yr[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ow = ow0 + u * L.rowthreads;
                         if (ow < g.Wo) {
                             const int iw = g.tabW ? g.tabW[ow] : ow;
-                            load_f<T, VEC>(xl + (size_t)iw * g.C, xv[u]);
+                            xr[u] = load_raw<T, VEC>(xl + (size_t)iw * g.C);
                             if (MODE == 1) {
-                                load_f<T, VEC>(dy + dl + (size_t)ow * g.C, dv[u]);
-                                if (y != nullptr) load_f<T, VEC>(y + dl + (size_t)ow * g.C, yv[u]);
+                                dr[u] = load_raw<T, VEC>(dy + dl + (size_t)ow * g.C);
+                                if (y != nullptr) yr[u] = load_raw<T, VEC>(y + dl + (size_t)ow * g.C);
                             }
                         }
                     }
@@ -77,17 +77,22 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
                     for (int u = 0; u < 4; ++u) {
                         const int ow = ow0 + u * L.rowthreads;
                         if (ow < g.Wo) {
+                            float xv[VEC];
+                            cvt_f<T, VEC>(xr[u], xv);
                             if (MODE == 0) {
 #pragma unroll
-                                for (int i = 0; i < VEC; ++i) { s[i] += xv[u][i]; q[i] += xv[u][i] * xv[u][i]; }
+                                for (int i = 0; i < VEC; ++i) { s[i] += xv[i]; q[i] += xv[i] * xv[i]; }
                             } else {
+                                float dv[VEC], yv[VEC];
+                                cvt_f<T, VEC>(dr[u], dv);
+                                if (y != nullptr) cvt_f<T, VEC>(yr[u], yv);
 #pragma unroll
                                 for (int i = 0; i < VEC; ++i) {
-                                    const bool dead = (y != nullptr && !(yv[u][i] > 0.f)) ||
-                                                      (remask && !(xv[u][i] * fa[i] + fs[i] > 0.f));
-                                    const float d = dead ? 0.f : dv[u][i];
+                                    const bool dead = (y != nullptr && !(yv[i] > 0.f)) ||
+                                                      (remask && !(xv[i] * fa[i] + fs[i] > 0.f));
+                                    const float d = dead ? 0.f : dv[i];
                                     s[i] += d;
-                                    q[i] += d * (xv[u][i] - mu[i]);
+                                    q[i] += d * (xv[i] - mu[i]);
                                 }
                             }
                         }

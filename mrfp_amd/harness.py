@@ -48,6 +48,7 @@ class FlatArena:
             self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + p.numel()].view(p.shape)
             p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+            p._mrfp_direct = True          # backward kernels may write this gradient slot directly (ops.grad_sink)
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -110,8 +111,16 @@ class GradSync:
         self.works = []
         self.on_gpu = opt.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None
+        self._index = {id(p): i for i, p in enumerate(opt.params)}
         for i, p in enumerate(opt.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
+        from . import ops
+        ops.GRAD_NOTIFY[0] = self._notify     # gradients written straight into the arena by the HIP backward kernels
+
+    def _notify(self, param):
+        i = self._index.get(id(param))
+        if i is not None:
+            self._make_hook(i)(param)
 
     def _make_hook(self, i):
         def hook(_param):

@@ -20,6 +20,24 @@ from ._lib import call, dt, ptr, stream
 
 CL = torch.channels_last
 
+# Direct gradient sinks: when the harness has placed a parameter's .grad inside its flat fp32 arena
+# (harness.FlatArena sets `_mrfp_direct`), backward kernels write the parameter gradient straight into that view
+# (no temporary, no autograd accumulate kernel) and report it through GRAD_NOTIFY (data-parallel bucket counting).
+GRAD_NOTIFY = [None]
+
+
+def grad_sink(param):
+    """The tensor a backward kernel should write d(param) into, or None for the ordinary autograd return path."""
+    if param is not None and getattr(param, "_mrfp_direct", False) and param.grad is not None \
+            and param.grad.dtype == torch.float32 and param.grad.is_contiguous():
+        return param.grad
+    return None
+
+
+def notify_grad(param):
+    if GRAD_NOTIFY[0] is not None:
+        GRAD_NOTIFY[0](param)
+
 
 # ------------------------------------------------------------------------------------------
 # layout helpers
@@ -182,6 +200,7 @@ class _BatchNormAct(torch.autograd.Function):
         # stored output is the only place the sign lives.
         keep_y = relu and res is not None
         ctx.remask = relu and res is None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, y if keep_y else None, w32, mean, invstd, A, S)
         return y
 
@@ -197,9 +216,17 @@ class _BatchNormAct(torch.autograd.Function):
         nslab, ws = _stats_bwd(dy, x, y, mean, False, plan, fA, fS)
         out = torch.empty(5 * C, dtype=torch.float32, device=dy.device)
         dw, db, P, Q, R = (out[i * C:(i + 1) * C] for i in range(5))
+        sw = grad_sink(ctx.wparam) if ctx.needs_input_grad[1] else None
+        sb = grad_sink(ctx.bparam) if ctx.needs_input_grad[2] else None
         call("mrfp_bn_bwd_finalize", ptr(ws), B, nslab, B * Ho * Wo, C, ptr(w32), ptr(mean), ptr(invstd),
-             ptr(dw), ptr(db), ptr(P), ptr(Q), ptr(R), stream())
+             ptr(sw if sw is not None else dw), ptr(sb if sb is not None else db), ptr(P), ptr(Q), ptr(R), stream())
         dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x, fA, fS)
+        if sw is not None:
+            notify_grad(ctx.wparam)
+            dw = None
+        if sb is not None:
+            notify_grad(ctx.bparam)
+            db = None
         return dx, dw, db, None, None, dres, None, None, None, None, None
 
 
@@ -227,6 +254,7 @@ class _InstanceNormAct(torch.autograd.Function):
              ptr(invstd), ptr(A), ptr(S), stream())
         y = _affine_fwd(x, None, A, S, True, relu, None)
         ctx.relu, ctx.affine = relu, weight is not None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, w32, mean, invstd, A, S)
         return y
 
@@ -241,12 +269,21 @@ class _InstanceNormAct(torch.autograd.Function):
         n = B * C
         P, Q, R = pqr[0:n], pqr[n:2 * n], pqr[2 * n:3 * n]
         dwb = torch.empty(2 * C, dtype=torch.float32, device=dy.device)
+        sw = grad_sink(ctx.wparam) if ctx.affine else None
+        sb = grad_sink(ctx.bparam) if ctx.affine else None
         call("mrfp_in_bwd_finalize", ptr(ws), B, nslab, H * W, C, ptr(w32), ptr(mean), ptr(invstd),
-             ptr(dwb[:C]), ptr(dwb[C:]), ptr(P), ptr(Q), ptr(R), stream())
+             ptr(sw if sw is not None else dwb[:C]), ptr(sb if sb is not None else dwb[C:]), ptr(P), ptr(Q), ptr(R), stream())
         dx, _ = _affine_bwd(dy, x, None, P, Q, R, True, None, False, x, fA, fS)
-        if ctx.affine:
-            return dx, dwb[:C], dwb[C:], None, None
-        return dx, None, None, None, None
+        if not ctx.affine:
+            return dx, None, None, None, None
+        dw, db = dwb[:C], dwb[C:]
+        if sw is not None:
+            notify_grad(ctx.wparam)
+            dw = None
+        if sb is not None:
+            notify_grad(ctx.bparam)
+            db = None
+        return dx, dw, db, None, None
 
 
 def instance_norm_act(x, weight, bias, *, eps=1e-5, relu=False):
