@@ -181,6 +181,8 @@ int mrfp_argmax_hist(const void* logits, const int64_t* target, int dtype, int64
  *   output position o reads source position o*stride - pad + r*dil; with sstride > 1 the tap
  *   exists only where that position is a multiple of sstride (then index = position / sstride):
  *   this is the dgrad of a strided convolution, run on dy with the wd pack.
+ *   addend (optional, same shape / pitch / dtype as y) is added in the epilogue: the gradient of a skip
+ *   connection is accumulated by the dgrad launch itself instead of a separate elementwise pass.
  *   C*sizeof(dtype) must be a multiple of 16 (pad the channels).
  * mrfp_conv_wgrad: dw[N][Ctrue][R][S] (fp32, OIHW) = sum over pixels of dy[.,n] * x[tap(.),c];
  *   ws: mrfp_conv_wgrad_ws_bytes(M = B*Ho*Wo, N, Q = R*S*C) bytes of scratch (split-K slabs,
@@ -192,7 +194,7 @@ int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, i
 int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype,
                   int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,
                   int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil,
-                  int64_t sstride, void* stream);
+                  int64_t sstride, const void* addend, void* stream);
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q);
 int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype,
                     int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,

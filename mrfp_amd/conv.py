@@ -73,22 +73,30 @@ def _out_size(H, R, stride, pad, dil):
 
 
 class _Conv2d(torch.autograd.Function):
+    """want_skip: also return an alias of x for a skip connection; the gradient arriving on that alias is added by
+    the dgrad kernel's epilogue (no separate accumulation pass over the activation)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad_h, pad_w, dil, Nphys):
+    def forward(ctx, x, weight, bias, stride, pad_h, pad_w, dil, Nphys, want_skip):
         B, Cphys, H, W = x.shape
         N, C, R, S = weight.shape
         Ho, Wo = _out_size(H, R, stride, pad_h, dil), _out_size(W, S, stride, pad_w, dil)
         pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
         y = empty_cl(B, Nphys, Ho, Wo, x.dtype, x.device)
         call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
-             Ho, Wo, stride, pad_h, pad_w, dil, 1, stream())
+             Ho, Wo, stride, pad_h, pad_w, dil, 1, None, stream())
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, pad_h, pad_w, dil, Nphys, Ho, Wo)
+        ctx.set_materialize_grads(False)
+        if want_skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, weight, bias = ctx.saved_tensors
+        if dy is None:            # only the skip alias was used downstream
+            return dskip, None, None, None, None, None, None, None, None
         stride, pad_h, pad_w, dil, Nphys, Ho, Wo = ctx.cfg
         dy = _chk(dy, "dy")
         B, Cphys, H, W = x.shape
@@ -99,8 +107,12 @@ class _Conv2d(torch.autograd.Function):
                 raise _lib.MrfpHipError("dgrad through a channel-padded input is not supported")
             pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
             dx = empty_cl(B, Cphys, H, W, x.dtype, x.device)
+            if dskip is not None:
+                dskip = _chk(dskip, "dskip")
+                if dskip.dtype != x.dtype:
+                    dskip = dskip.to(x.dtype)
             call("mrfp_conv_fwd", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
-                 1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, stream())
+                 1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), stream())
         if ctx.needs_input_grad[1]:
             M, Q = B * Ho * Wo, R * S * Cphys
             ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
@@ -120,7 +132,7 @@ class _Conv2d(torch.autograd.Function):
             call("mrfp_bn_finalize", ptr(sws), B, nslab, B * Ho * Wo, Nphys, None, None, 0.0, 0.0, None, None,
                  ptr(out[:Nphys]), ptr(out[Nphys:2 * Nphys]), ptr(out[2 * Nphys:3 * Nphys]), ptr(out[3 * Nphys:]), stream())
             db = (out[:N] * float(B * Ho * Wo)).to(bias.dtype)       # column mean * count = column sum
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def pad_input_channels(x: torch.Tensor, dtype) -> torch.Tensor:
@@ -137,9 +149,10 @@ def pad_input_channels(x: torch.Tensor, dtype) -> torch.Tensor:
     return y
 
 
-def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] = None):
+def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] = None, want_skip: bool = False):
     """x: [B,Cphys,H,W] channels-last (Cphys >= weight.shape[1], extra channels must be zero);
-    returns [B,N,Ho,Wo], or the channel-padded [B,phys_out,Ho,Wo] buffer when phys_out is given."""
+    returns [B,N,Ho,Wo], or the channel-padded [B,phys_out,Ho,Wo] buffer when phys_out is given.
+    want_skip: returns (y, x_skip) -- see _Conv2d."""
     st = stride[0] if isinstance(stride, (tuple, list)) else int(stride)
     ph, pw = (padding if isinstance(padding, (tuple, list)) else (int(padding), int(padding)))
     dl = dilation[0] if isinstance(dilation, (tuple, list)) else int(dilation)
@@ -152,7 +165,8 @@ def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] =
     if x.shape[1] < C:
         raise _lib.MrfpHipError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], C))
     Nphys = phys_out if phys_out is not None else _round_up(N, epc)
-    y = _Conv2d.apply(x, weight, bias, st, ph, pw, dl, Nphys)
+    out = _Conv2d.apply(x, weight, bias, st, ph, pw, dl, Nphys, want_skip)
+    y, skip = out if want_skip else (out, None)
     if phys_out is None and Nphys != N:
         y = y[:, :N].contiguous(memory_format=CL)
-    return y
+    return (y, skip) if want_skip else y

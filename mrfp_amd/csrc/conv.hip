@@ -33,6 +33,7 @@ struct ConvP {
     const char* w;      // packed weight [N][kchunks] 16-byte chunks
     char* y;            // output [M][ldy]
     const float* bias;  // [N] or null
+    const char* addend; // [M][ldy] (T) added to the result in the epilogue, or null (fused gradient accumulation)
     int B, H, W, C;
     int N, ldy;
     int R, S, Ho, Wo;
@@ -264,8 +265,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
             const int row = k * RPI + lane / CPRW, ch = lane % CPRW;
             const int m = mb + row, n = nb + ch * EPC;
             if (m < p.M && n < p.N) {
-                const uint4 v = *reinterpret_cast<const uint4*>(ep + row * EPITCH + ch * 16);
+                uint4 v = *reinterpret_cast<const uint4*>(ep + row * EPITCH + ch * 16);
                 T* dst = y + (size_t)m * p.ldy + n;
+                if (p.addend) {      // y += addend (the skip-connection gradient): one 16-byte read instead of a separate add pass
+                    const T* ad = reinterpret_cast<const T*>(p.addend) + (size_t)m * p.ldy + n;
+                    T* tv = reinterpret_cast<T*>(&v);
+                    if (n + EPC <= p.N) {
+                        const uint4 av = *reinterpret_cast<const uint4*>(ad);
+                        const T* ta = reinterpret_cast<const T*>(&av);
+#pragma unroll
+                        for (int u = 0; u < EPC; ++u) tv[u] = from_f<T>(to_f(tv[u]) + to_f(ta[u]));
+                    } else {
+                        for (int u = 0; u < EPC && n + u < p.N; ++u) tv[u] = from_f<T>(to_f(tv[u]) + to_f(ad[u]));
+                    }
+                }
                 if (n + EPC <= p.N) {
                     *reinterpret_cast<uint4*>(dst) = v;
                 } else {
@@ -378,7 +391,9 @@ extern "C" {
 
 int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
                   int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
-                  int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, void* stream) {
+                  int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
+                  void* stream) {
+    MRFP_CHECK(!addend || aligned16(addend), "conv_fwd: addend must be 16-byte aligned");
     MRFP_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
                "conv_fwd: bad arguments");
     MRFP_CHECK(stride >= 1 && dil >= 1 && sstride >= 1 && ldy >= N, "conv_fwd: bad stride/dilation/pitch");
@@ -388,7 +403,7 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
     MRFP_CHECK(aligned16(x) && aligned16(wpack), "conv_fwd: x / wpack must be 16-byte aligned");
     MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
     ConvP p;
-    p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias;
+    p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias; p.addend = (const char*)addend;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;

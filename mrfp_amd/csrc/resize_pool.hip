@@ -66,11 +66,14 @@ __device__ __forceinline__ float ac_weight(float scale, int dst, int in, int src
     const Tap t = ac_tap(scale, dst, in);
     return (t.i0 == src ? t.l0 : 0.f) + (t.i1 == src ? t.l1 : 0.f);
 }
-// candidate destination range that can touch source index `src` (one index of slack on both sides)
-__device__ __forceinline__ void ac_range(float scale, int src, int out, int& lo, int& hi) {
-    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
-    lo = (int)floorf((float)(src - 1) / scale) - 1;
-    hi = (int)ceilf((float)(src + 1) / scale) + 1;
+// destination range that can touch source index `src`: src-1 < dst*(in-1)/(out-1) < src+1, in exact integer
+// arithmetic (a destination whose float position rounds onto the open boundary carries a weight of ~1 ulp; every
+// candidate's weight is re-evaluated with the forward's float expression, so the range only bounds the work)
+__device__ __forceinline__ void ac_range(int in, int out, int src, int& lo, int& hi) {
+    if (in <= 1 || out <= 1) { lo = 0; hi = out - 1; return; }
+    const long long a = in - 1, b = out - 1;
+    lo = src >= 1 ? (int)(((long long)(src - 1) * b) / a) : 0;            // floor((src-1)*b/a): weight may be 0, cheap
+    hi = (int)(((long long)(src + 1) * b + a - 1) / a);                     // ceil((src+1)*b/a)
     if (lo < 0) lo = 0;
     if (hi > out - 1) hi = out - 1;
 }
@@ -87,10 +90,10 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restr
     for (int cv = tcol; cv < L.lpr; cv += kThreads) {
         for (int ih = j; ih < Hi; ih += ly) {
             int oh0, oh1;
-            ac_range(sh, ih, Ho, oh0, oh1);
+            ac_range(Hi, Ho, ih, oh0, oh1);
             for (int iw = trow; iw < Wi; iw += L.rowthreads) {
                 int ow0, ow1;
-                ac_range(sw, iw, Wo, ow0, ow1);
+                ac_range(Wi, Wo, iw, ow0, ow1);
                 float acc[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;

@@ -65,6 +65,13 @@ class _Block(nn.Module):
             return None, None
         return x_tuple[0], x_tuple[1]
 
+    def _first_conv(self, x):
+        """conv1(x) and the tensor the skip connection should read: an alias of x whose gradient the conv1 dgrad
+        kernel accumulates (identity blocks), or x itself (blocks with a downsample branch)."""
+        if self.downsample is None:
+            return self.conv1.forward_skip(x)
+        return self.conv1(x), x
+
     def _tail(self, last_bn, out, x, w_arr):
         residual = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))
         if self.iw >= 1:
@@ -92,8 +99,9 @@ class BasicBlock(_Block):
         x, w_arr = self._unpack(x_tuple)
         if x is None:
             return None
-        out = self.bn1.fused(self.conv1(x), relu=True)
-        return self._tail(self.bn2, self.conv2(out), x, w_arr)
+        out, skip = self._first_conv(x)
+        out = self.bn1.fused(out, relu=True)
+        return self._tail(self.bn2, self.conv2(out), skip, w_arr)
 
 
 class Bottleneck(_Block):
@@ -115,9 +123,10 @@ class Bottleneck(_Block):
         x, w_arr = self._unpack(x_tuple)
         if x is None:
             return None
-        out = self.bn1.fused(self.conv1(x), relu=True)
+        out, skip = self._first_conv(x)
+        out = self.bn1.fused(out, relu=True)
         out = self.bn2.fused(self.conv2(out), relu=True)
-        return self._tail(self.bn3, self.conv3(out), x, w_arr)
+        return self._tail(self.bn3, self.conv3(out), skip, w_arr)
 
 
 class _Trunk(nn.Module):

@@ -15,10 +15,27 @@ class HipBatchNorm2d(nn.BatchNorm2d):
     statistics + apply pair.  `fused(...)` lets the owning block fold the ReLU, the residual add and
     a preceding nearest resize into the same two passes."""
 
+    # num_batches_tracked is counted on the host and flushed into the buffer when the state dict is read:
+    # a 1-element device kernel per BatchNorm per step (122 launches) is pure launch overhead.
+    _nbt_pending = 0
+
+    def _flush_nbt(self):
+        if self._nbt_pending and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._nbt_pending)
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_nbt()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
     def fused(self, x, *, relu=False, res=None, plan=None):
         training = self.training or (self.running_mean is None)
         if training and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            self._nbt_pending += 1
         return ops.batch_norm_act(x, self.weight, self.bias,
                                   self.running_mean if self.track_running_stats else None,
                                   self.running_var if self.track_running_stats else None,
@@ -44,6 +61,10 @@ class HipConv2d(nn.Conv2d):
 
     def forward(self, x):
         return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+
+    def forward_skip(self, x):
+        """(conv(x), x_skip): x_skip aliases x; its gradient is folded into this conv's dgrad launch."""
+        return ops.conv2d_skip(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
 
 
 def Norm2d(in_channels):

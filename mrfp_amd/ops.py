@@ -546,6 +546,17 @@ def as_activation(x: torch.Tensor) -> torch.Tensor:
     return to_cl(x)
 
 
+def conv2d_skip(x, weight, bias, stride, padding, dilation):
+    """(conv(x), alias of x for a skip connection): with the HIP backend the skip gradient is accumulated in the
+    dgrad epilogue; with the stock backend the alias is x itself."""
+    from .config import cfg
+    x = _chk(x)
+    if cfg.MODEL.CONV_BACKEND == "hip":
+        from . import conv
+        return conv.conv2d(x, weight, bias, stride, padding, dilation, None, True)
+    return conv2d(x, weight, bias, stride, padding, dilation), x
+
+
 def conv2d(x, weight, bias, stride, padding, dilation, phys_out=None):
     """nn.Conv2d forward/backward.  Backend 'hip': MFMA implicit-GEMM kernels (mrfp_amd/conv.py);
     backend 'miopen': stock ROCm convolution through ATen on the same NHWC tensors (BASELINE.json
