@@ -84,8 +84,9 @@ __device__ __forceinline__ uint4 bload(const __amdgpu_buffer_rsrc_t& r, unsigned
 //          filter tap and the tap (r,s) is tracked in scalar registers; otherwise every thread tracks the tap
 //          of its own 16-byte chunk.
 // STRIDED: dgrad of a strided convolution (taps exist only where the position divides the source stride).
+// 8-wave workgroups ask for 4 waves per SIMD (two co-resident workgroups per CU -> <= 128 registers per lane)
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_igemm_kernel(ConvP p) {
     constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -333,7 +334,18 @@ static int pick_igemm(const ConvP& p, hipStream_t st) {
 
 template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
+    // MRFP_CONV_BIGTILE=1 enables the 256x128 (8-wave) tile.  Measured on MI355X (16x192x192x256 -> 256, 3x3):
+    // 642 TF/s vs 786 TF/s for the 128x128 tile -- to keep two 8-wave workgroups per CU the compiler has to fit
+    // 128 registers and spills 18; off by default until the staging moves to LDS-DMA.
+    static int big = -1;
+    if (big < 0) {
+        const char* e = getenv("MRFP_CONV_BIGTILE");
+        big = e ? atoi(e) : 0;
+    }
     if (p.N <= 64) return pick_igemm<T, 4, 1>(p, st);
+    // 256x128 tile, 8 waves: 25 % fewer operand bytes per FLOP and twice the MFMA work per K step and CU to hide
+    // the global-load latency behind; only when there are enough 256-row tiles to fill the chip
+    if (big && sizeof(T) == 2 && (int64_t)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 512) return pick_igemm<T, 4, 2>(p, st);
     return pick_igemm<T, 2, 2>(p, st);
 }
 

@@ -1,0 +1,30 @@
+"""Micro-benchmark of single convolution shapes through the C ABI (for rocprofv3 --pmc runs)."""
+import sys, os, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mrfp_amd import conv
+from mrfp_amd.config import cfg
+cfg.MODEL.ACT_DTYPE = torch.bfloat16
+which = sys.argv[1] if len(sys.argv) > 1 else "big3x3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+shapes = {"big3x3": (16, 256, 192, 192, 256, 3, 1, 1, 1), "l3_3x3": (16, 256, 48, 48, 256, 3, 1, 1, 1),
+          "l3_1x1": (16, 1024, 48, 48, 256, 1, 1, 0, 1), "hrfp": (16, 128, 384, 384, 256, 3, 1, 1, 1)}
+B, C, H, W, N, k, st, pad, dil = shapes[which]
+x = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+w = (torch.randn(N, C, k, k, device="cuda") * 0.05).requires_grad_(True)
+y = conv.conv2d(x, w, None, st, pad, dil)
+gy = torch.randn_like(y)
+mode = sys.argv[3] if len(sys.argv) > 3 else "fwd"
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    if mode == "fwd":
+        with torch.no_grad():
+            y = conv.conv2d(x, w, None, st, pad, dil)
+    else:
+        y = conv.conv2d(x, w, None, st, pad, dil)
+        y.backward(gy)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+fl = 2.0 * B * (H // st) * (W // st) * N * C * k * k * (1 if mode == "fwd" else 3)
+print(which, mode, "%.3f ms  %.1f TF/s" % (dt * 1e3, fl / dt / 1e12))
