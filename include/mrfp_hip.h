@@ -165,6 +165,16 @@ int mrfp_ce_fwd(const void* logits, const int64_t* target, int dtype, int64_t np
 int mrfp_ce_bwd(const void* logits, const int64_t* target, const float* loss, const float* gscale,
                 void* dlogits, int dtype, int64_t npix, int64_t C, int64_t ignore_index, void* stream);
 
+/* Fused bilinear upsample (align_corners) of the channel-padded low-resolution class scores P[B,Hi,Wi,ld]
+ * + cross entropy at [B,H,W] (reference deepv3.py:361-365: in training only the scalar loss is needed, so the
+ * full-resolution logits are never written).  ws / loss as mrfp_ce_fwd (npix = B*H*W).
+ * bwd writes d(logits)[B,H,W,Cd] (Cd = C rounded up to a 16-byte chunk, pad channels zero) for mrfp_bilinear_bwd. */
+int mrfp_upsample_ce_fwd(const void* P, int64_t ld, const int64_t* target, int dtype, int64_t B, int64_t Hi, int64_t Wi,
+                         int64_t H, int64_t W, int64_t C, int64_t ignore_index, float* ws, float* loss, void* stream);
+int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const float* loss, const float* gscale,
+                         void* dlogits, int64_t Cd, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
+                         int64_t C, int64_t ignore_index, void* stream);
+
 /* Eval: argmax over classes + 19x19 confusion histogram on the device (reference main.py:898-909,
  * metrics.py:122-126): hist[num_classes*gt + pred] += 1 for gt in [0,num_classes).  hist: int64
  * [C*C], accumulated (not cleared).  pred (optional, uint8 [npix]) receives the arg-max. */

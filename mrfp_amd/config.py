@@ -51,6 +51,8 @@ cfg.MODEL.BNFUNC = None
 cfg.MODEL.ACT_DTYPE = torch.float32
 # 'hip' = hand-written MFMA implicit-GEMM kernels; 'miopen' = stock ROCm convolution through ATen
 cfg.MODEL.CONV_BACKEND = "hip"
+# training: fuse final bilinear upsample + cross entropy (the full-resolution logits are never written)
+cfg.MODEL.FUSE_UPSAMPLE_CE = True
 # directory searched for ImageNet checkpoints when pretrained=True (no network access here)
 cfg.MODEL.PRETRAINED_DIR = None
 

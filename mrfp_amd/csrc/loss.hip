@@ -173,3 +173,156 @@ int mrfp_argmax_hist(const void* logits, const int64_t* target, int dtype, int64
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Fused  bilinear upsample (align_corners) of the low-resolution class scores  +  cross entropy.
+// In training the reference only needs the scalar loss (deepv3.py:361-365): the full-resolution
+// [B,19,H,W] logits are never written; every thread re-interpolates the 4 taps of its pixel from the
+// (L2-resident) low-resolution scores.  Backward writes d(logits) once, channel-padded to a 16-byte
+// multiple, for the gather-form bilinear backward.
+// =============================================================================================
+namespace mrfp {
+
+__device__ __forceinline__ float up_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+template <typename T>
+__device__ __forceinline__ void up_logits(const T* __restrict__ P, int ld, int Hi, int Wi, int H, int W, int C, int b,
+                                          int oh, int ow, float (&z)[kMaxClasses]) {
+    const float sh = up_scale(Hi, H), sw = up_scale(Wi, W);
+    const float fh = sh * (float)oh, fw = sw * (float)ow;
+    const int h0 = (int)fh, w0 = (int)fw;
+    const int h1 = h0 + (h0 < Hi - 1 ? 1 : 0), w1 = w0 + (w0 < Wi - 1 ? 1 : 0);
+    const float lh1 = fh - (float)h0, lh0 = 1.f - lh1, lw1 = fw - (float)w0, lw0 = 1.f - lw1;
+    const T* p00 = P + (((size_t)b * Hi + h0) * Wi + w0) * ld;
+    const T* p01 = P + (((size_t)b * Hi + h0) * Wi + w1) * ld;
+    const T* p10 = P + (((size_t)b * Hi + h1) * Wi + w0) * ld;
+    const T* p11 = P + (((size_t)b * Hi + h1) * Wi + w1) * ld;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    for (int c0 = 0; c0 < C; c0 += EPC) {
+        float a[EPC], bb[EPC], c[EPC], d[EPC];
+        load_f<T, EPC>(p00 + c0, a);
+        load_f<T, EPC>(p01 + c0, bb);
+        load_f<T, EPC>(p10 + c0, c);
+        load_f<T, EPC>(p11 + c0, d);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i)
+            if (c0 + i < C) z[c0 + i] = lh0 * (lw0 * a[i] + lw1 * bb[i]) + lh1 * (lw0 * c[i] + lw1 * d[i]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kCeThreads) void upsample_ce_fwd_kernel(const T* __restrict__ P, int ld, const int64_t* __restrict__ target,
+                                                                     int B, int Hi, int Wi, int H, int W, int C, int64_t ignore,
+                                                                     float* __restrict__ ws) {
+    __shared__ float sm[2][kCeThreads / 64];
+    const int64_t npix = (int64_t)B * H * W;
+    float nll = 0.f, cnt = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * kCeThreads + threadIdx.x; p < npix; p += (int64_t)gridDim.x * kCeThreads) {
+        const int64_t tg = target[p];
+        if (tg == ignore || tg < 0 || tg >= C) continue;
+        const int b = (int)(p / ((int64_t)H * W)), rem = (int)(p - (int64_t)b * H * W);
+        const int oh = rem / W, ow = rem - oh * W;
+        float z[kMaxClasses];
+        up_logits<T>(P, ld, Hi, Wi, H, W, C, b, oh, ow, z);
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+        float s = 0.f, zt = 0.f;
+        for (int c = 0; c < C; ++c) { s += __expf(z[c] - m); zt = (c == (int)tg) ? z[c] : zt; }
+        nll += (m + __logf(s)) - zt;
+        cnt += 1.f;
+    }
+    nll = wave_sum(nll);
+    cnt = wave_sum(cnt);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[0][w] = nll; sm[1][w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, bsum = 0.f;
+        for (int i = 0; i < kCeThreads / 64; ++i) { a += sm[0][i]; bsum += sm[1][i]; }
+        ws[2 * blockIdx.x] = a;
+        ws[2 * blockIdx.x + 1] = bsum;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kCeThreads) void upsample_ce_bwd_kernel(const T* __restrict__ P, int ld, const int64_t* __restrict__ target,
+                                                                     const float* __restrict__ loss, const float* __restrict__ gscale,
+                                                                     T* __restrict__ dlogits, int Cd, int B, int Hi, int Wi, int H,
+                                                                     int W, int C, int64_t ignore) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int64_t npix = (int64_t)B * H * W;
+    const float k = (gscale ? gscale[0] : 1.f) / loss[1];
+    for (int64_t p = (int64_t)blockIdx.x * kCeThreads + threadIdx.x; p < npix; p += (int64_t)gridDim.x * kCeThreads) {
+        const int64_t tg = target[p];
+        T* d = dlogits + p * Cd;
+        float g[kMaxClasses];
+        const bool valid = !(tg == ignore || tg < 0 || tg >= C);
+        if (valid) {
+            const int b = (int)(p / ((int64_t)H * W)), rem = (int)(p - (int64_t)b * H * W);
+            const int oh = rem / W, ow = rem - oh * W;
+            up_logits<T>(P, ld, Hi, Wi, H, W, C, b, oh, ow, g);
+            float m = -INFINITY;
+            for (int c = 0; c < C; ++c) m = fmaxf(m, g[c]);
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) { g[c] = __expf(g[c] - m); s += g[c]; }
+            const float inv = 1.f / s;
+            for (int c = 0; c < C; ++c) g[c] = (g[c] * inv - (c == (int)tg ? 1.f : 0.f)) * k;
+        }
+        for (int c0 = 0; c0 < Cd; c0 += EPC) {
+            float o[EPC];
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) o[i] = (valid && c0 + i < C) ? g[c0 + i] : 0.f;
+            store_f<T, EPC>(d + c0, o);
+        }
+    }
+}
+
+}  // namespace mrfp
+
+extern "C" {
+
+int mrfp_upsample_ce_fwd(const void* P, int64_t ld, const int64_t* target, int dtype, int64_t B, int64_t Hi, int64_t Wi,
+                         int64_t H, int64_t W, int64_t C, int64_t ignore_index, float* ws, float* loss, void* stream) {
+    MRFP_CHECK(P && target && ws && loss && B > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0 && C > 0 && C <= mrfp::kMaxClasses,
+               "upsample_ce_fwd: bad arguments");
+    const int esz = dtype == MRFP_F32 ? 4 : 2, epc = 16 / esz;
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "upsample_ce_fwd: unknown dtype %d", dtype);
+    MRFP_CHECK(ld % epc == 0 && ld >= (C + epc - 1) / epc * epc && mrfp::aligned16(P),
+               "upsample_ce_fwd: the score buffer must be channel-padded to 16-byte chunks (ld=%lld)", (long long)ld);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = mrfp::ce_blocks(B * H * W);
+    if (dtype == MRFP_F32)
+        hipLaunchKernelGGL((mrfp::upsample_ce_fwd_kernel<float>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const float*)P, (int)ld,
+                           target, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C, ignore_index, ws);
+    else
+        hipLaunchKernelGGL((mrfp::upsample_ce_fwd_kernel<mrfp::bf16>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const mrfp::bf16*)P,
+                           (int)ld, target, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C, ignore_index, ws);
+    MRFP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mrfp::ce_finalize_kernel, dim3(1), dim3(256), 0, st, ws, nb, loss);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const float* loss, const float* gscale,
+                         void* dlogits, int64_t Cd, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
+                         int64_t C, int64_t ignore_index, void* stream) {
+    MRFP_CHECK(P && target && loss && dlogits && B > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0 && C > 0 && C <= mrfp::kMaxClasses,
+               "upsample_ce_bwd: bad arguments");
+    const int esz = dtype == MRFP_F32 ? 4 : 2, epc = 16 / esz;
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "upsample_ce_bwd: unknown dtype %d", dtype);
+    MRFP_CHECK(ld % epc == 0 && Cd % epc == 0 && Cd >= C && ld >= Cd && mrfp::aligned16(P) && mrfp::aligned16(dlogits),
+               "upsample_ce_bwd: channel pitches must be 16-byte multiples (ld=%lld Cd=%lld)", (long long)ld, (long long)Cd);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = mrfp::ce_blocks(B * H * W);
+    if (dtype == MRFP_F32)
+        hipLaunchKernelGGL((mrfp::upsample_ce_bwd_kernel<float>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const float*)P, (int)ld,
+                           target, loss, gscale, (float*)dlogits, (int)Cd, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C, ignore_index);
+    else
+        hipLaunchKernelGGL((mrfp::upsample_ce_bwd_kernel<mrfp::bf16>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const mrfp::bf16*)P,
+                           (int)ld, target, loss, gscale, (mrfp::bf16*)dlogits, (int)Cd, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
+                           ignore_index);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -163,19 +163,29 @@ class _DeepLabBase(nn.Module):
         d = self.final1[1].fused(self.final1[0](d), relu=True)
         return self.final1[4].fused(self.final1[3](d), relu=True)
 
-    def _logits(self, dec1, size):
-        """final2 (1x1 conv + bias) then bilinear upsample to the input size (reference
-        deepv3.py:360-361).  The low-resolution logits live in a 32-channel padded buffer so the conv
-        stays chunk-aligned; only the full-resolution tensor has the odd class count."""
+    def _plain_ce(self):
+        c = self.criterion
+        return isinstance(c, nn.CrossEntropyLoss) and c.weight is None and c.reduction == "mean" and c.label_smoothing == 0.0
+
+    def _head(self, dec1, size, gts, training):
+        """final2 (1x1 conv + bias) -> bilinear upsample to the input size -> loss or logits (reference
+        deepv3.py:360-367).  The low-resolution class scores live in a 32-channel padded buffer so the conv stays
+        chunk-aligned; in training with the plain CE criterion the upsample and the loss are one kernel and the
+        full-resolution logits are never written."""
         f2 = self.final2[0]
         nc = f2.out_channels
-        pitch = (nc + 31) // 32 * 32 if cfg.MODEL.CONV_BACKEND == "hip" else None
+        hip = cfg.MODEL.CONV_BACKEND == "hip"
+        pitch = (nc + 31) // 32 * 32 if hip else None
         dec2 = ops.conv2d(dec1, f2.weight, f2.bias, f2.stride, f2.padding, f2.dilation, phys_out=pitch)
-        return ops.upsample_bilinear(dec2, size, channels=nc)
+        if training and hip and cfg.MODEL.FUSE_UPSAMPLE_CE and self._plain_ce():
+            return ops.upsample_cross_entropy(dec2, gts, size, nc, self.criterion.ignore_index)
+        main_out = ops.upsample_bilinear(dec2, size, channels=nc)
+        if training:
+            return self._loss(main_out, gts)
+        return main_out.float()
 
     def _loss(self, main_out, gts):
-        if isinstance(self.criterion, nn.CrossEntropyLoss) and self.criterion.weight is None \
-                and self.criterion.reduction == "mean" and self.criterion.label_smoothing == 0.0:
+        if self._plain_ce():
             return ops.cross_entropy(main_out, gts, self.criterion.ignore_index)
         return self.criterion(main_out.float(), gts)
 
@@ -268,10 +278,7 @@ class MRFPPlus(_DeepLabBase):
         dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))
         if o2:                                         # "+" of MRFP+: deepv3.py:355-357, one fused pass
             dec1 = ops.upsample_bilinear(dec1, (int(h / 2), int(w / 2)), addend=OCout_dec)
-        main_out = self._logits(dec1, (h, w))
-        if training:
-            return self._loss(main_out, gts)
-        return main_out.float()
+        return self._head(dec1, (h, w), gts, training)
 
 
 class simpleDeepV3Plus(_DeepLabBase):
@@ -300,7 +307,4 @@ class simpleDeepV3Plus(_DeepLabBase):
         dec0_fine = self.bot_fine(low_level)
         dec0_up = Upsample(dec0_up, low_level.shape[2:])
         dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))
-        main_out = self._logits(dec1, (h, w))
-        if training:
-            return self._loss(main_out, gts)
-        return main_out.float()
+        return self._head(dec1, (h, w), gts, training)

@@ -492,6 +492,48 @@ def cross_entropy(logits, target, ignore_index=255):
     return _CrossEntropy.apply(logits, target, ignore_index)
 
 
+class _UpsampleCrossEntropy(torch.autograd.Function):
+    """loss = CE(Upsample(P[:, :C], size), target) without materialising the full-resolution logits
+    (reference deepv3.py:361-365 in training mode)."""
+
+    @staticmethod
+    def forward(ctx, P, target, H, W, C, ignore_index):
+        P = _chk(P, "P")
+        B, ld, Hi, Wi = P.shape
+        target = target.contiguous()
+        if target.dtype != torch.int64 or tuple(target.shape) != (B, H, W):
+            raise _lib.MrfpHipError("upsample_cross_entropy: target must be int64 [B,H,W]")
+        npix = B * H * W
+        nblk = int(_lib.lib().mrfp_ce_nblocks(npix))
+        ws = torch.empty(2 * nblk, dtype=torch.float32, device=P.device)
+        loss = torch.empty(2, dtype=torch.float32, device=P.device)
+        call("mrfp_upsample_ce_fwd", ptr(P), ld, ptr(target), dt(P), B, Hi, Wi, H, W, C, int(ignore_index), ptr(ws),
+             ptr(loss), stream())
+        ctx.save_for_backward(P, target, loss)
+        ctx.cfg = (H, W, C, int(ignore_index))
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        P, target, loss = ctx.saved_tensors
+        H, W, C, ignore = ctx.cfg
+        B, ld, Hi, Wi = P.shape
+        epc = 16 // P.element_size()
+        Cd = (C + epc - 1) // epc * epc
+        gs = g.detach().float().reshape(1).contiguous()
+        dlog = empty_cl(B, Cd, H, W, P.dtype, P.device)
+        call("mrfp_upsample_ce_bwd", ptr(P), ld, ptr(target), ptr(loss), ptr(gs), ptr(dlog), Cd, dt(P), B, Hi, Wi, H, W, C,
+             ignore, stream())
+        dP = empty_cl(B, ld, Hi, Wi, P.dtype, P.device) if ld == Cd else zeros_cl(B, ld, Hi, Wi, P.dtype, P.device)
+        call("mrfp_bilinear_bwd", ptr(dlog), ptr(dP), dt(P), B, Hi, Wi, H, W, Cd, ld, stream())
+        return dP, None, None, None, None, None
+
+
+def upsample_cross_entropy(P, target, size, channels, ignore_index=255):
+    """P: channel-padded low-resolution class scores [B,ld,Hi,Wi] (ld a multiple of the 16-byte chunk)."""
+    return _UpsampleCrossEntropy.apply(P, target, int(size[0]), int(size[1]), int(channels), ignore_index)
+
+
 # ------------------------------------------------------------------------------------------
 # eval: arg-max + confusion histogram on the device
 # ------------------------------------------------------------------------------------------

@@ -277,3 +277,28 @@ def test_cpu_input_fails_loudly():
     o = ops()
     with pytest.raises(_lib.MrfpHipError):
         o.relu(torch.zeros(1, 8, 2, 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [((2, 19, 12, 10), (48, 40)), ((1, 19, 7, 9), (25, 33)), ((2, 19, 16, 16), (16, 16))])
+def test_fused_upsample_cross_entropy(dtype, case):
+    """upsample + CE fused (no full-resolution logits) == Upsample() then CrossEntropyLoss(255) on the CPU."""
+    o = ops()
+    (B, C, Hi, Wi), (H, W) = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, Hi, Wi, generator=g) * 2
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    y[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    xc = x.clone().requires_grad_(True)
+    lc = orc.cross_entropy_255(orc.upsample_bilinear_ac(xc, (H, W)), y)
+    (lc * 0.7).backward()
+    P = torch.zeros(B, 32, Hi, Wi)
+    P[:, :C] = x
+    Pd = P.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ld = o.upsample_cross_entropy(Pd, y.to(DEV), (H, W), C, 255)
+    (ld * 0.7).backward()
+    assert abs(ld.item() - lc.item()) / abs(lc.item()) < (1e-5 if dtype == torch.float32 else 2e-3)
+    assert relerr(Pd.grad[:, :C], xc.grad) < (2e-5 if dtype == torch.float32 else 1.5e-2)
+    assert float(Pd.grad[:, C:].abs().max()) == 0.0
