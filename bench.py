@@ -74,8 +74,10 @@ def cpu_baseline(args, seconds):
     import json as js
     from mrfp_amd import synth
     from oracle import mrfp_oracle as orc
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); more threads than that only contend
+    cores = int(os.environ.get("MRFP_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
+    print("[bench] cpu_baseline: oracle on %d host threads ..." % cores, file=sys.stderr, flush=True)
     from mrfp_amd import deepv3
     from mrfp_amd.config import cfg
     m = deepv3.MRFPPlus(19, trunk=args.trunk)
@@ -96,13 +98,15 @@ def cpu_baseline(args, seconds):
         work.update(leaf)
         loss = orc.mrfp_forward(work, x, y, training=True, toggles=(True, True, True), noise=noise)
         torch.autograd.grad(loss, [leaf[k] for k in keys])
-    step()
+    t0 = time.time()
+    step()                                         # warm-up (allocator, oneDNN primitive caches)
+    first = time.time() - t0
+    print("[bench] cpu_baseline: warm-up step %.1f s" % first, file=sys.stderr, flush=True)
     t0, n = time.time(), 0
-    while n < 3 or time.time() - t0 < seconds:
+    while n < 2 or (time.time() - t0 < seconds and n < 50):
         step()
         n += 1
-        if time.time() - t0 > 3 * seconds:
-            break
+        print("[bench] cpu_baseline: step %d at %.1f s" % (n, time.time() - t0), file=sys.stderr, flush=True)
     dt_ = time.time() - t0
     return {"value": round(B * n / dt_, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d train steps (fwd+bwd) of %s MRFP+ at %dx%dx%d fp32 on the CPU oracle; "
