@@ -84,10 +84,17 @@ __device__ __forceinline__ uint4 bload(const __amdgpu_buffer_rsrc_t& r, unsigned
 //          filter tap and the tap (r,s) is tracked in scalar registers; otherwise every thread tracks the tap
 //          of its own 16-byte chunk.
 // STRIDED: dgrad of a strided convolution (taps exist only where the position divides the source stride).
-// 8-wave workgroups ask for 4 waves per SIMD (two co-resident workgroups per CU -> <= 128 registers per lane)
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_igemm_kernel(ConvP p) {
-    constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
+// WM x WN waves per workgroup, every wave owns TM x TN accumulator blocks of 32x32 (2x2 = 64x64 per wave, 64
+// accumulator registers, three waves per SIMD; 4x2 = 128x64 per wave, 128 accumulator registers, two waves per
+// SIMD: half the LDS reads and half the L2->LDS bytes per FLOP, and twice the MFMA work per K step to hide the
+// global-load latency behind -- used where the problem has enough 256-row tiles to fill the chip).
+// DMA: tiles go global -> LDS directly (buffer_load ... lds, no staging registers, no ds_write traffic); the LDS
+//      image of one wave-instruction is lane-linear (base + lane*16), so the XOR swizzle is applied to the SOURCE
+//      chunk each lane fetches; needs NBUF == 2 (the DMA of tile k+1 lands while tile k is multiplied).
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 1)) void conv_igemm_kernel(ConvP p) {
+    static_assert(!DMA || NBUF == 2, "LDS-DMA staging needs two LDS buffers");
+    constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA0 = smem;
@@ -99,7 +106,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_ige
     const int ntn = (p.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int chunk = t & 7, rbase = t >> 3;
+    const int rbase = t >> 3;
+    const int chunk = DMA ? ((t & 7) ^ ((rbase >> 1) & 7)) : (t & 7);   // SOURCE chunk of this thread's slots
+    const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;          // first tile row of this wave's DMA pieces
     const int pixbytes = p.C * (int)sizeof(T);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
@@ -140,7 +149,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_ige
     }
     const int tiles_per_tap = p.cpr >> 3;
 
-    auto load_tile = [&](int kt, uint4 (&ra)[SA], uint4 (&rb)[SB]) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto load_tile = [&](int kt, uint4 (&ra)[SA], uint4 (&rb)[SB], int dbuf) {
         const int dh = tr * p.dil, dw = ts * p.dil;
         const int cc = ALIGNED ? tc * 8 + chunk : tc;
         const bool qok = ALIGNED ? true : tr < p.R;
@@ -159,16 +169,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_ige
                 const bool ok = qok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 voff = ok ? a_base[i] + tap : kOOB;
             }
-            ra[i] = bload(xr, voff);
+            if (DMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sA0 + dbuf * BUF + (wrow + i * RSTEP) * 128), 16,
+                                                         (int)voff, 0, 0, 0);
+            else
+                ra[i] = bload(xr, voff);
         }
-        const unsigned qoff = qok ? (unsigned)(kt * 8 + chunk) * 16u : kOOB;
+        // weight-pack chunk of this K tile: taps are the INNER loop when ALIGNED (see the advance below)
+        const unsigned qoff = !qok ? kOOB
+                              : ALIGNED ? (unsigned)((tr * p.S + ts) * p.cpr + tc * 8 + chunk) * 16u
+                                        : (unsigned)(kt * 8 + chunk) * 16u;
 #pragma unroll
-        for (int i = 0; i < SB; ++i) rb[i] = bload(wr, (b_base[i] >= kOOB || !qok) ? kOOB : b_base[i] + qoff);
-        // advance to the next K tile
+        for (int i = 0; i < SB; ++i) {
+            const unsigned voff = (b_base[i] >= kOOB || !qok) ? kOOB : b_base[i] + qoff;
+            if (DMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sB0 + dbuf * BUF + (wrow + i * RSTEP) * 128), 16,
+                                                         (int)voff, 0, 0, 0);
+            else
+                rb[i] = bload(wr, voff);
+        }
+        // advance to the next K tile.  ALIGNED: channel chunk OUTER, filter tap INNER -- the R*S taps of one 64-channel
+        // slab re-read (shifted) the same input pixels back to back, so 8 of 9 reads of a 3x3 convolution are served
+        // by the XCD's L2 instead of the fabric (the working set of a tap-outer order, 3 image rows x all channels x
+        // 32 workgroups, does not fit the 4 MiB L2; measured: the 256x256 kernel was fill-bound at 6.3 TB/s).
         if (ALIGNED) {
-            if (++tc == tiles_per_tap) {
-                tc = 0;
-                if (++ts == p.S) { ts = 0; ++tr; }
+            if (++ts == p.S) {
+                ts = 0;
+                if (++tr == p.R) { tr = 0; ++tc; }
             }
         } else {
             tc += 8;
@@ -187,47 +214,62 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_ige
         for (int i = 0; i < SB; ++i) *reinterpret_cast<uint4*>(b + lds_off(rbase + i * RSTEP, chunk)) = rb[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nkt = (p.kchunks + 7) >> 3;
     uint4 ra[SA], rb[SB];
-    load_tile(0, ra, rb);
-    store_tile(0, ra, rb);
-    __syncthreads();
     const int lr = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = NBUF == 2 ? (kt & 1) : 0;
-        if (kt + 1 < nkt) load_tile(kt + 1, ra, rb);
+    auto compute = [&](int buf) {
         const char* a = sA0 + buf * BUF;
         const char* b = sB0 + buf * BUF;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int ch = kk * 2 + lh;
-            uint4 fa[2], fb[2];
+            uint4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const uint4*>(a + lds_off(wm * 64 + i * 32 + lr, ch));
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(a + lds_off(wm * 32 * TM + i * 32 + lr, ch));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 64 + j * 32 + lr, ch));
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 32 * TN + j * 32 + lr, ch));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
-        if (NBUF == 2) {
-            if (kt + 1 < nkt) store_tile(buf ^ 1, ra, rb);
+    };
+    if (DMA) {
+        // tile k+1 streams into the other LDS buffer while tile k is multiplied; __syncthreads() = vmcnt(0) (this
+        // wave's DMA pieces have landed) + barrier (so have everybody else's, and everybody is done reading tile k)
+        load_tile(0, ra, rb, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) load_tile(kt + 1, ra, rb, (kt + 1) & 1);
+            compute(kt & 1);
             __syncthreads();
-        } else {
-            // single LDS buffer (half the LDS -> one more workgroup per CU): the prefetched tile waits in
-            // registers until every wave has finished reading the current one
-            __syncthreads();
-            if (kt + 1 < nkt) store_tile(0, ra, rb);
-            __syncthreads();
+        }
+    } else {
+        load_tile(0, ra, rb, 0);
+        store_tile(0, ra, rb);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = NBUF == 2 ? (kt & 1) : 0;
+            if (kt + 1 < nkt) load_tile(kt + 1, ra, rb, 0);
+            compute(buf);
+            if (NBUF == 2) {
+                if (kt + 1 < nkt) store_tile(buf ^ 1, ra, rb);
+                __syncthreads();
+            } else {
+                // single LDS buffer (half the LDS -> one more workgroup per CU): the prefetched tile waits in
+                // registers until every wave has finished reading the current one
+                __syncthreads();
+                if (kt + 1 < nkt) store_tile(0, ra, rb);
+                __syncthreads();
+            }
         }
     }
 
@@ -236,23 +278,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_ige
     // wave transposes its tile through LDS (free after the K loop) 32 rows at a time and writes whole 16-byte
     // chunks of output rows, 8 (bf16) / 4 (fp32) rows per wave-instruction, fully coalesced.
     constexpr int EPC = 16 / (int)sizeof(T);              // elements per 16-byte chunk
-    constexpr int ROWB = 64 * (int)sizeof(T);             // bytes of one 64-column tile row
+    constexpr int ROWB = 32 * TN * (int)sizeof(T);        // bytes of one row of the wave's tile
     constexpr int EPITCH = ROWB + 16;                      // +16: the two lane halves (rows r, r+4) hit disjoint banks
     constexpr int CPRW = ROWB / 16;                        // chunks per row (8 / 16)
     constexpr int RPI = 64 / CPRW;                         // rows per wave-instruction (8 / 4)
     char* const ep = smem + wave * (32 * EPITCH);          // 4.5 KB (bf16) / 8.5 KB (fp32) per wave
     T* y = reinterpret_cast<T*>(p.y);
-    const int nb = n0 + wn * 64;
-    float bv[2];
+    const int nb = n0 + wn * 32 * TN;
+    float bv[TN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
         const int n = nb + j * 32 + lr;
         bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -260,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_ige
             }
         // same-wave LDS round trip: no workgroup barrier needed, only the wave's own LDS ops must have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // also a compiler barrier (T stores vs uint4 loads)
-        const int mb = m0 + wm * 64 + i * 32;
+        const int mb = m0 + wm * 32 * TM + i * 32;
 #pragma unroll
         for (int k = 0; k < 32 / RPI; ++k) {
             const int row = k * RPI + lane / CPRW, ch = lane % CPRW;
@@ -292,61 +334,70 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv_ige
     }
 }
 
-static int g_nbuf = 0;   // 0 = pick per shape; 1 / 2 forced (MRFP_CONV_NBUF, for A/B measurements)
-
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF>
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
 static int launch_igemm_nb(const ConvP& p, hipStream_t st) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int EP = 64 * WM * WN / 64 * 32 * (64 * (int)sizeof(T) + 16);     // epilogue staging
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int EP = WM * WN * 32 * (32 * TN * (int)sizeof(T) + 16);     // epilogue staging
     const int lds = NBUF * (BM + BN) * 128 > EP ? NBUF * (BM + BN) * 128 : EP;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF, TM, TN, DMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF>), dim3((unsigned)tiles),
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF, TM, TN, DMA>), dim3((unsigned)tiles),
                        dim3(64 * WM * WN), lds, st, p);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
 
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED>
+static int g_nbuf = 0;   // 0 = unset; 1 / 2 forced through MRFP_CONV_NBUF (for A/B measurements); default 1
+
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int TM, int TN>
 static int launch_igemm(const ConvP& p, hipStream_t st) {
     if (g_nbuf == 0) {
         const char* e = getenv("MRFP_CONV_NBUF");
-        g_nbuf = e ? atoi(e) : 3;
-        if (g_nbuf < 1 || g_nbuf > 3) g_nbuf = 3;
+        g_nbuf = e ? atoi(e) : 1;
+        if (g_nbuf != 2) g_nbuf = 1;   // default (measured on MI355X): single buffer, 3 workgroups per CU
     }
-    int nb = g_nbuf;
-    if (nb == 3) nb = 1;   // default (measured on MI355X): single buffer, 3 workgroups per CU
-    return nb == 1 ? launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1>(p, st)
-                   : launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2>(p, st);
+    static int dma = -1;      // MRFP_CONV_DMA: 0 = register staging everywhere, 1 = LDS-DMA for the 128x64-per-wave tiles
+    if (dma < 0) {            //               2 = LDS-DMA for every tile shape
+        const char* e = getenv("MRFP_CONV_DMA");
+        dma = e ? atoi(e) : 1;
+    }
+    if ((dma == 1 && TM * TN >= 8) || dma == 2) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
+    if (TM * TN >= 8 || g_nbuf == 1) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, false>(p, st);
+    return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, false>(p, st);
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int TM, int TN>
 static int pick_igemm(const ConvP& p, hipStream_t st) {
     const bool aligned = (p.cpr & 7) == 0, strided = p.sstride > 1;
-    if (aligned) return strided ? launch_igemm<T, WM, WN, true, true>(p, st) : launch_igemm<T, WM, WN, true, false>(p, st);
-    return strided ? launch_igemm<T, WM, WN, false, true>(p, st) : launch_igemm<T, WM, WN, false, false>(p, st);
+    if (aligned) return strided ? launch_igemm<T, WM, WN, true, true, TM, TN>(p, st) : launch_igemm<T, WM, WN, true, false, TM, TN>(p, st);
+    return strided ? launch_igemm<T, WM, WN, false, true, TM, TN>(p, st) : launch_igemm<T, WM, WN, false, false, TM, TN>(p, st);
 }
 
 template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
-    // MRFP_CONV_BIGTILE=1 enables the 256x128 (8-wave) tile.  Measured on MI355X (16x192x192x256 -> 256, 3x3):
-    // 642 TF/s vs 786 TF/s for the 128x128 tile -- to keep two 8-wave workgroups per CU the compiler has to fit
-    // 128 registers and spills 18; off by default until the staging moves to LDS-DMA.
+    // MRFP_CONV_BIGTILE=0 disables the 128x64-per-wave tiles (A/B measurements)
     static int big = -1;
     if (big < 0) {
         const char* e = getenv("MRFP_CONV_BIGTILE");
-        big = e ? atoi(e) : 0;
+        big = e ? atoi(e) : 1;
     }
-    if (p.N <= 64) return pick_igemm<T, 4, 1>(p, st);
-    // 256x128 tile, 8 waves: 25 % fewer operand bytes per FLOP and twice the MFMA work per K step and CU to hide
-    // the global-load latency behind; only when there are enough 256-row tiles to fill the chip
-    if (big && sizeof(T) == 2 && (int64_t)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 512) return pick_igemm<T, 4, 2>(p, st);
-    return pick_igemm<T, 2, 2>(p, st);
+    if (p.N <= 64) return pick_igemm<T, 4, 1, 2, 2>(p, st);
+    if (big && sizeof(T) == 2) {
+        // 256x256 tile (8 waves x 128x64, LDS-DMA, one workgroup per CU).  Measured per shape on MI355X inside the
+        // bench workload (bench.py --dump-convs): +8..10 % on long-K 3x3 layers with >= 2 full rounds of tiles
+        // (998 vs 913 TF/s at 16x192x192x256->256), but -25 % with ~1 round (M = 36 864), -20 % on short-K 1x1
+        // layers (fill / drain dominate) and on N that wastes most of the second 256-column tile; a 256x128
+        // 4-wave variant (254 VGPRs) lost 25 % everywhere and was dropped.
+        const int64_t m256 = (p.M + 255) / 256, n256 = (p.N + 255) / 256;
+        const int nkt = (p.kchunks + 7) >> 3;
+        if (p.N >= 192 && n256 * 256 - p.N <= 64 && nkt >= 18 && m256 * n256 >= 448) return pick_igemm<T, 2, 4, 4, 2>(p, st);
+    }
+    return pick_igemm<T, 2, 2, 2, 2>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,6 +474,12 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
     const int64_t xb = B * H * W * C * esz, wb = N * (int64_t)p.kchunks * 16;
     MRFP_CHECK(xb < (int64_t)kOOB && wb < (int64_t)kOOB, "conv_fwd: tensor exceeds the 3.75 GB buffer-descriptor range");
     p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
+    {   // timing-only diagnostics: zero-record descriptors drop that operand's traffic, instruction stream unchanged
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
+        if (dbg & 1) p.xbytes = 0;
+        if (dbg & 2) p.wbytes = 0;
+    }
     if (dtype == MRFP_F32) return run_igemm<float>(p, (hipStream_t)stream);
     return run_igemm<bf16>(p, (hipStream_t)stream);
 }

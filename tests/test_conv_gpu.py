@@ -26,6 +26,10 @@ CASES = [
     (2, 256, 12, 10, 48, 1, 1, 0, 1, False),     # bot_fine
     (2, 256, 12, 10, 19, 1, 1, 0, 1, True),      # final2 (N padded to a chunk)
     (3, 64, 33, 31, 64, 3, 1, 1, 1, False),      # M not a multiple of the tile
+    (2, 128, 240, 240, 256, 3, 1, 1, 1, True),   # enough rows and K tiles for the 256x256 (8-wave, LDS-DMA) tile
+    (2, 128, 240, 236, 256, 3, 1, 2, 2, False),  # 256x256 tile, dilated, ragged M
+    (2, 1152, 244, 240, 256, 1, 1, 0, 1, False), # 256x256 tile on a 1x1 conv with 18 K tiles
+    (2, 304, 240, 240, 256, 3, 1, 1, 1, False),  # big tile with taps straddling K tiles (304 channels)
 ]
 
 
