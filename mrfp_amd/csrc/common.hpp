@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/mrfp_hip.h"
 
 namespace mrfp {
@@ -121,7 +122,13 @@ inline int lines_per_image(int64_t B, int64_t Ho) {
     // ~1024 workgroups over the chip (4 per CU, 16 waves/CU, 4 independent 16-byte loads per lane in the
     // statistics kernels): enough bytes in flight to cover HBM latency, few enough partial sums that the
     // finalize kernels stay in the microseconds.
-    int64_t cap = 1024 / (B > 0 ? B : 1);
+    static int total = 0;
+    if (total == 0) {
+        const char* e = getenv("MRFP_ROW_BLOCKS");
+        total = e ? atoi(e) : 2048;
+        if (total < 64) total = 2048;
+    }
+    int64_t cap = total / (B > 0 ? B : 1);
     if (cap < 1) cap = 1;
     return (int)(Ho < cap ? Ho : cap);
 }

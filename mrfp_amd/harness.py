@@ -108,6 +108,7 @@ class GradSync:
             for i in mem:
                 self.bucket_of[i] = b
         self.pending = [0] * len(self.buckets)
+        self.seen = [False] * len(opt.params)
         self.works = []
         self.on_gpu = opt.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None
@@ -124,6 +125,12 @@ class GradSync:
 
     def _make_hook(self, i):
         def hook(_param):
+            # A parameter can be reported twice in one step: by the HIP backward kernel that wrote its gradient
+            # straight into the arena (ops.notify_grad) and by autograd's post-accumulate hook (this PyTorch fires
+            # it even when the backward returned None for the parameter).  Count each parameter once.
+            if self.seen[i]:
+                return
+            self.seen[i] = True
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
@@ -144,6 +151,7 @@ class GradSync:
     def begin(self):
         if self.enabled:
             self.pending = [len(m) for _, _, m in self.buckets]
+            self.seen = [False] * len(self.opt.params)
             self.works = []
 
     def finish(self):

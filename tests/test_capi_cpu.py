@@ -25,7 +25,7 @@ def test_header_symbols_exported(cdll):
 
 
 def test_host_only_entry_points(cdll):
-    assert cdll.mrfp_stats_nslab(16, 384) == 64
+    assert cdll.mrfp_stats_nslab(16, 384) == 128
     assert cdll.mrfp_stats_nslab(2, 64) == 64
     assert 1 <= cdll.mrfp_ce_nblocks(10) <= 2048 and cdll.mrfp_ce_nblocks(1 << 30) == 2048
     # argument validation happens on the host before any launch
