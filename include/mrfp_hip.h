@@ -204,7 +204,17 @@ int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, i
 int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype,
                   int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,
                   int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil,
-                  int64_t sstride, const void* addend, void* stream);
+                  int64_t sstride, const void* addend, float* colstats, void* stream);
+/* colstats (optional): the epilogue also writes per-channel partial sums of the STORED output,
+ * float [nblk][2][ldy] (sum, sum of squares per row block), nblk = mrfp_conv_stats_blocks(...): the
+ * BatchNorm statistics pass over the conv output disappears (feed it to mrfp_bn_finalize with B = 1,
+ * nslab = nblk, count = B*Ho*Wo). */
+int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S);
+/* colstats must hold mrfp_conv_stats_rows(nblk) rows of 2*ldy floats; large launches fold their row blocks into
+ * 64 groups appended behind them: hand rows [final_first, final_first + final_count) to mrfp_bn_finalize. */
+int64_t mrfp_conv_stats_rows(int64_t nblk);
+int64_t mrfp_conv_stats_final_first(int64_t nblk);
+int64_t mrfp_conv_stats_final_count(int64_t nblk);
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q);
 int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype,
                     int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,

@@ -17,6 +17,9 @@ from ._lib import call, dt, ptr, stream
 from .ops import CL, _chk, empty_cl, grad_sink, notify_grad, zeros_cl
 
 _PACKS = {}      # id(weight Parameter) -> {key: _Pack}; entry dropped when the Parameter dies
+import os as _os
+FUSE_STATS = [_os.environ.get("MRFP_FUSE_STATS", "1") != "0"]   # conv epilogues emit BatchNorm partial statistics for bias-free convolutions
+_LAST_STATS = [None]  # handed from _Conv2d.forward to conv2d() (autograd re-wraps the output tensor object)
 _EPOCH = [0]     # bumped by writers that bypass autograd's version counters (the fused SGD kernel)
 
 
@@ -83,8 +86,19 @@ class _Conv2d(torch.autograd.Function):
         Ho, Wo = _out_size(H, R, stride, pad_h, dil), _out_size(W, S, stride, pad_w, dil)
         pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
         y = empty_cl(B, Nphys, Ho, Wo, x.dtype, x.device)
+        stats = None
+        if bias is None and FUSE_STATS[0]:
+            # no bias = a convolution that feeds a normalisation layer: let the epilogue produce its statistics
+            L = _lib.lib()
+            nblk = int(L.mrfp_conv_stats_blocks(dt(x), B * Ho * Wo, Nphys, Cphys, R, S))
+            stats = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Nphys, dtype=torch.float32, device=x.device)
         call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
-             Ho, Wo, stride, pad_h, pad_w, dil, 1, None, stream())
+             Ho, Wo, stride, pad_h, pad_w, dil, 1, None, ptr(stats), stream())
+        if stats is not None:      # the rows the BatchNorm finalize should read (compacted for large launches)
+            first, cnt = int(L.mrfp_conv_stats_final_first(nblk)), int(L.mrfp_conv_stats_final_count(nblk))
+            _LAST_STATS[0] = (stats[first * 2 * Nphys:(first + cnt) * 2 * Nphys], cnt, B * Ho * Wo)
+        else:
+            _LAST_STATS[0] = None
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, pad_h, pad_w, dil, Nphys, Ho, Wo)
         ctx.set_materialize_grads(False)
@@ -112,7 +126,7 @@ class _Conv2d(torch.autograd.Function):
                 if dskip.dtype != x.dtype:
                     dskip = dskip.to(x.dtype)
             call("mrfp_conv_fwd", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
-                 1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), stream())
+                 1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), None, stream())
         if ctx.needs_input_grad[1]:
             M, Q = B * Ho * Wo, R * S * Cphys
             ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
@@ -165,8 +179,12 @@ def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] =
     if x.shape[1] < C:
         raise _lib.MrfpHipError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], C))
     Nphys = phys_out if phys_out is not None else _round_up(N, epc)
+    _LAST_STATS[0] = None
     out = _Conv2d.apply(x, weight, bias, st, ph, pw, dl, Nphys, want_skip)
     y, skip = out if want_skip else (out, None)
+    if _LAST_STATS[0] is not None and (phys_out is not None or Nphys == N):
+        y._mrfp_colstats = _LAST_STATS[0]        # consumed by ops.batch_norm_act (statistics pass skipped)
+    _LAST_STATS[0] = None
     if phys_out is None and Nphys != N:
         y = y[:, :N].contiguous(memory_format=CL)
     return (y, skip) if want_skip else y

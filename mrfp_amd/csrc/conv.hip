@@ -34,6 +34,7 @@ struct ConvP {
     char* y;            // output [M][ldy]
     const float* bias;  // [N] or null
     const char* addend; // [M][ldy] (T) added to the result in the epilogue, or null (fused gradient accumulation)
+    float* colstats;    // [row blocks][2][ldy] per-channel sum / sum of squares of the stored output, or null
     int B, H, W, C;
     int N, ldy;
     int R, S, Ho, Wo;
@@ -285,11 +286,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 1)) void conv_ige
     char* const ep = smem + wave * (32 * EPITCH);          // 4.5 KB (bf16) / 8.5 KB (fp32) per wave
     T* y = reinterpret_cast<T*>(p.y);
     const int nb = n0 + wn * 32 * TN;
-    float bv[TN];
+    float bv[TN], cs[TN], cq[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = nb + j * 32 + lr;
         bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        cs[j] = 0.f;
+        cq[j] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -298,7 +301,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 1)) void conv_ige
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = from_f<T>(acc[i][j][e] + bv[j]);
+                const T sv = from_f<T>(acc[i][j][e] + bv[j]);
+                *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = sv;
+                if (p.colstats) {      // BatchNorm statistics of the STORED (rounded) values, fused into the producer
+                    const float fv = (m0 + wm * 32 * TM + i * 32 + row < p.M) ? to_f(sv) : 0.f;
+                    cs[j] += fv;
+                    cq[j] += fv * fv;
+                }
             }
         // same-wave LDS round trip: no workgroup barrier needed, only the wave's own LDS ops must have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // also a compiler barrier (T stores vs uint4 loads)
@@ -332,6 +341,39 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 1)) void conv_ige
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (p.colstats) {
+        // a lane holds 16 of the 32 rows of each block column, its partner (lane ^ 32) the other 16
+        float* out = p.colstats + (size_t)((tile / ntn) * WM + wm) * 2 * p.ldy;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float s2 = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
+            const int n = nb + j * 32 + lr;
+            if (lh == 0 && n < p.N) {
+                out[n] = s2;
+                out[p.ldy + n] = q2;
+            }
+        }
+    }
+}
+
+// Folds the per-row-block statistics [nblk][2][C] of a forward launch into kStatGroups rows (appended after row
+// nblk) so that the BatchNorm finalize kernel walks 64 partials per channel instead of thousands.
+constexpr int kStatGroups = 64;
+__global__ void compact_stats_kernel(float* __restrict__ st, int nblk, int C2) {   // C2 = 2*C floats per row
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (c >= C2) return;
+    const int per = (nblk + kStatGroups - 1) / kStatGroups;
+    const int r0 = g * per, r1 = min(nblk, r0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        a0 += st[(size_t)r * C2 + c];
+        a1 += st[(size_t)(r + 1) * C2 + c];
+        a2 += st[(size_t)(r + 2) * C2 + c];
+        a3 += st[(size_t)(r + 3) * C2 + c];
+    }
+    for (; r < r1; ++r) a0 += st[(size_t)r * C2 + c];
+    st[(size_t)(nblk + g) * C2 + c] = (a0 + a1) + (a2 + a3);
 }
 
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
@@ -378,25 +420,33 @@ static int pick_igemm(const ConvP& p, hipStream_t st) {
     return strided ? launch_igemm<T, WM, WN, false, true, TM, TN>(p, st) : launch_igemm<T, WM, WN, false, false, TM, TN>(p, st);
 }
 
+static int g_big = -1;
+static bool use_big_tile(const ConvP& p, int esz) {
+    if (g_big < 0) {
+        const char* e = getenv("MRFP_CONV_BIGTILE");    // MRFP_CONV_BIGTILE=0 disables the 256x256 tile (A/B measurements)
+        g_big = e ? atoi(e) : 1;
+    }
+    if (!g_big || esz != 2 || p.N <= 64) return false;
+    const int64_t m256 = (p.M + 255) / 256, n256 = (p.N + 255) / 256;
+    const int nkt = (p.kchunks + 7) >> 3;
+    return p.N >= 192 && n256 * 256 - p.N <= 64 && nkt >= 18 && m256 * n256 >= 448;
+}
+// number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
+static int64_t stats_row_blocks(const ConvP& p, int esz) {
+    if (p.N <= 64) return (int64_t)((p.M + 255) / 256) * 4;          // <4,1,2,2>: 256-row tile, 4 wave rows
+    if (use_big_tile(p, esz)) return (int64_t)((p.M + 255) / 256) * 2;  // <2,4,4,2>: 256-row tile, 2 wave rows
+    return (int64_t)((p.M + 127) / 128) * 2;                          // <2,2,2,2>: 128-row tile, 2 wave rows
+}
+
 template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
-    // MRFP_CONV_BIGTILE=0 disables the 128x64-per-wave tiles (A/B measurements)
-    static int big = -1;
-    if (big < 0) {
-        const char* e = getenv("MRFP_CONV_BIGTILE");
-        big = e ? atoi(e) : 1;
-    }
     if (p.N <= 64) return pick_igemm<T, 4, 1, 2, 2>(p, st);
-    if (big && sizeof(T) == 2) {
-        // 256x256 tile (8 waves x 128x64, LDS-DMA, one workgroup per CU).  Measured per shape on MI355X inside the
-        // bench workload (bench.py --dump-convs): +8..10 % on long-K 3x3 layers with >= 2 full rounds of tiles
-        // (998 vs 913 TF/s at 16x192x192x256->256), but -25 % with ~1 round (M = 36 864), -20 % on short-K 1x1
-        // layers (fill / drain dominate) and on N that wastes most of the second 256-column tile; a 256x128
-        // 4-wave variant (254 VGPRs) lost 25 % everywhere and was dropped.
-        const int64_t m256 = (p.M + 255) / 256, n256 = (p.N + 255) / 256;
-        const int nkt = (p.kchunks + 7) >> 3;
-        if (p.N >= 192 && n256 * 256 - p.N <= 64 && nkt >= 18 && m256 * n256 >= 448) return pick_igemm<T, 2, 4, 4, 2>(p, st);
-    }
+    // 256x256 tile (8 waves x 128x64, LDS-DMA, one workgroup per CU).  Measured per shape on MI355X inside the
+    // bench workload (bench.py --dump-convs): +8..10 % on long-K 3x3 layers with >= 2 full rounds of tiles
+    // (998 vs 913 TF/s at 16x192x192x256->256), but -25 % with ~1 round (M = 36 864), -20 % on short-K 1x1
+    // layers (fill / drain dominate) and on N that wastes most of the second 256-column tile; a 256x128
+    // 4-wave variant (254 VGPRs) lost 25 % everywhere and was dropped.
+    if (use_big_tile(p, (int)sizeof(T))) return pick_igemm<T, 2, 4, 4, 2>(p, st);
     return pick_igemm<T, 2, 2, 2, 2>(p, st);
 }
 
@@ -455,7 +505,7 @@ extern "C" {
 int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
                   int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
                   int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
-                  void* stream) {
+                  float* colstats, void* stream) {
     MRFP_CHECK(!addend || aligned16(addend), "conv_fwd: addend must be 16-byte aligned");
     MRFP_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
                "conv_fwd: bad arguments");
@@ -466,7 +516,7 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
     MRFP_CHECK(aligned16(x) && aligned16(wpack), "conv_fwd: x / wpack must be 16-byte aligned");
     MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
     ConvP p;
-    p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias; p.addend = (const char*)addend;
+    p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias; p.addend = (const char*)addend; p.colstats = colstats;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
@@ -480,9 +530,29 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
         if (dbg & 1) p.xbytes = 0;
         if (dbg & 2) p.wbytes = 0;
     }
-    if (dtype == MRFP_F32) return run_igemm<float>(p, (hipStream_t)stream);
-    return run_igemm<bf16>(p, (hipStream_t)stream);
+    const int rc = dtype == MRFP_F32 ? run_igemm<float>(p, (hipStream_t)stream) : run_igemm<bf16>(p, (hipStream_t)stream);
+    if (rc || !colstats) return rc;
+    const int64_t nblk = stats_row_blocks(p, esz);
+    if (nblk > 2 * kStatGroups) {
+        const int C2 = 2 * (int)ldy;
+        hipLaunchKernelGGL(compact_stats_kernel, dim3((unsigned)((C2 + 255) / 256), kStatGroups), dim3(256), 0,
+                           (hipStream_t)stream, colstats, (int)nblk, C2);
+        MRFP_LAUNCH_CHECK();
+    }
+    return 0;
 }
+
+int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S) {
+    ConvP p;
+    const int esz = dtype == MRFP_F32 ? 4 : 2;
+    p.M = (int)M; p.N = (int)N; p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    return stats_row_blocks(p, esz);
+}
+/* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */
+int64_t mrfp_conv_stats_rows(int64_t nblk) { return nblk > 2 * kStatGroups ? nblk + kStatGroups : nblk; }
+/* where the rows to hand to mrfp_bn_finalize start, and how many there are */
+int64_t mrfp_conv_stats_final_first(int64_t nblk) { return nblk > 2 * kStatGroups ? nblk : 0; }
+int64_t mrfp_conv_stats_final_count(int64_t nblk) { return nblk > 2 * kStatGroups ? kStatGroups : nblk; }
 
 int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, int64_t C, int64_t R, int64_t S,
                      int64_t Npad, int64_t Cpad, void* stream) {

@@ -187,8 +187,14 @@ class _BatchNormAct(torch.autograd.Function):
         coef = torch.empty(4 * C, dtype=torch.float32, device=dev)
         mean, invstd, A, S = coef[0:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:4 * C]
         if training:
-            nslab, ws = _stats_fwd(x, plan)
-            call("mrfp_bn_finalize", ptr(ws), B, nslab, B * Ho * Wo, C, ptr(w32), ptr(b32), float(eps),
+            fused = getattr(x, "_mrfp_colstats", None) if plan is None else None
+            if fused is not None and fused[2] == B * Ho * Wo and fused[0].numel() == fused[1] * 2 * C:
+                # the producing convolution already summed its output per channel in its epilogue
+                ws, nb_, nslab = fused[0], 1, fused[1]
+            else:
+                nslab, ws = _stats_fwd(x, plan)
+                nb_ = B
+            call("mrfp_bn_finalize", ptr(ws), nb_, nslab, B * Ho * Wo, C, ptr(w32), ptr(b32), float(eps),
                  float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(A), ptr(S), stream())
         else:
             call("mrfp_bn_eval_coef", C, ptr(w32), ptr(b32), ptr(running_mean), ptr(running_var), float(eps),

@@ -101,3 +101,29 @@ def test_padded_logits_path():
     yd.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
     assert relerr(yd, yc) < 1e-5 and relerr(xd.grad, xc.grad) < 1e-5
     assert relerr(wd.grad, wc.grad) < 1e-5 and relerr(bd.grad, bc.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 64, 20, 18, 128, 3), (3, 128, 33, 31, 64, 1), (2, 128, 240, 240, 256, 3)])
+def test_conv_epilogue_statistics_feed_batchnorm(dtype, case):
+    """BatchNorm statistics fused into the producing conv's epilogue == the separate statistics pass."""
+    from mrfp_amd import conv, ops
+    B, Cin, H, W, Cout, k = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).to(DEV)
+    gamma, beta = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV) * 0.1
+    conv.FUSE_STATS[0] = True
+    y1 = conv.conv2d(x, w, None, 1, k // 2, 1)
+    assert getattr(y1, "_mrfp_colstats", None) is not None
+    rm1, rv1 = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    z1 = ops.batch_norm_act(y1, gamma, beta, rm1, rv1, training=True, relu=True)
+    conv.FUSE_STATS[0] = False
+    y2 = conv.conv2d(x, w, None, 1, k // 2, 1)
+    assert getattr(y2, "_mrfp_colstats", None) is None
+    rm2, rv2 = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    z2 = ops.batch_norm_act(y2, gamma, beta, rm2, rv2, training=True, relu=True)
+    conv.FUSE_STATS[0] = True
+    assert torch.equal(y1, y2)
+    assert relerr(z1, z2) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert relerr(rm1, rm2) < 1e-5 and relerr(rv1, rv2) < 1e-4
