@@ -886,6 +886,12 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
     const int64_t xb = B * H * W * C * esz, yb = (int64_t)p.M * ldn * esz;
     MRFP_CHECK(xb < (int64_t)kOOB && yb < (int64_t)kOOB, "conv_wgrad: tensor exceeds the 3.75 GB buffer-descriptor range");
     p.xbytes = (unsigned)xb; p.dybytes = (unsigned)yb;
+    {   // timing-only diagnostics (see mrfp_conv_fwd)
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
+        if (dbg & 1) p.xbytes = 0;
+        if (dbg & 2) p.dybytes = 0;
+    }
     p.div_hw = make_fastdiv((unsigned)(Ho * Wo)); p.div_w = make_fastdiv((unsigned)Wo);
     int wm, splits;
     wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen);

@@ -21,10 +21,18 @@ for _ in range(reps):
     if mode == "fwd":
         with torch.no_grad():
             y = conv.conv2d(x, w, None, st, pad, dil)
+    elif mode == "wgrad":
+        from mrfp_amd import _lib
+        from mrfp_amd._lib import call, ptr, dt, stream
+        Ho, Wo = y.shape[2], y.shape[3]
+        if _ == 0:
+            ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(B * Ho * Wo, N, k * k * C)), dtype=torch.uint8, device="cuda")
+            dw = torch.empty(N, C, k, k, device="cuda")
+        call("mrfp_conv_wgrad", ptr(x), ptr(gy), ptr(dw), ptr(ws), dt(x), B, H, W, C, C, N, N, k, k, Ho, Wo, st, pad, pad, dil, stream())
     else:
         y = conv.conv2d(x, w, None, st, pad, dil)
         y.backward(gy)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
-fl = 2.0 * B * (H // st) * (W // st) * N * C * k * k * (1 if mode == "fwd" else 3)
+fl = 2.0 * B * (H // st) * (W // st) * N * C * k * k * (3 if mode == "all" else 1)
 print(which, mode, "%.3f ms  %.1f TF/s" % (dt * 1e3, fl / dt / 1e12))
