@@ -119,10 +119,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MRFP_FORCE_SYNC") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -147,22 +150,22 @@ def main():
     for _ in range(args.warmup):
         trainer.step(x, y)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(x, y)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    lossv = float(loss)
+    lossv = float(loss.detach())
 
     out = None
     if rank == 0:
@@ -182,7 +185,7 @@ def main():
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "conv_backend": args.backend, "final_loss": round(lossv, 5)},
                "roofline": roof}
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

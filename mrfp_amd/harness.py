@@ -14,6 +14,7 @@ process per MI355X:
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -90,7 +91,9 @@ class GradSync:
     def __init__(self, opt: FlatArena, bucket_mb: float = 32.0, group=None):
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        # MRFP_FORCE_SYNC=1: run the bucket / side-stream / collective machinery even with one rank (rehearsal of the
+        # multi-GPU path on a single-GPU box)
+        self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("MRFP_FORCE_SYNC") == "1")
         self.buckets: List[tuple] = []
         if not self.enabled:
             return
