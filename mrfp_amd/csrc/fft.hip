@@ -187,8 +187,298 @@ static int launch_pass(FftP p, int N, const float2* tw, int nlines, hipStream_t 
     return 0;
 }
 
+// =============================================================================================
+// Fast path: line lengths N = N1*N2 (N2 = 16 or 32) as a TWO-STEP transform held in registers.
+//   step A   thread (channel, n2) owns x[n1*N2 + n2], n1 < N1: an N1-point DFT in registers, then the twiddle W_N^(n2*k1)
+//   exchange one pass through LDS (the only one per line transform), padded pitch -> conflict-free 8-byte accesses
+//   step B   thread (channel, k1) owns the N2 values of row k1: an N2-point DFT in registers -> X[k1 + N1*k2]
+// Three launches instead of four, and the column launch does forward transform, amplitude mix and inverse transform
+// on one tile (the inverse starts from step B's register layout, so there is no exchange between them):
+//   rows      x  -> S          read 1 plane, write the half spectrum
+//   columns   S (+ the partner's column where the band reaches it) -> S3     (ratio written / read here)
+//   rows^-1   S3 -> y
+// Workgroups that share cache lines of the NHWC activation (the channel groups of one line) are numbered so that
+// they run back to back on the same XCD (one L2).
+// =============================================================================================
+__device__ __forceinline__ float2 tw96(int j) {       // exp(-2 pi i j / 96); j is a constant after unrolling
+    constexpr float kc[96] = {
+            1.f, 0.997858923f, 0.991444861f, 0.98078528f, 0.965925826f, 0.946930129f, 0.923879533f, 0.896872742f,
+            0.866025404f, 0.831469612f, 0.79335334f, 0.751839807f, 0.707106781f, 0.659345815f, 0.608761429f, 0.555570233f,
+            0.5f, 0.44228869f, 0.382683432f, 0.321439465f, 0.258819045f, 0.195090322f, 0.130526192f, 0.0654031292f,
+            0.f, -0.0654031292f, -0.130526192f, -0.195090322f, -0.258819045f, -0.321439465f, -0.382683432f, -0.44228869f,
+            -0.5f, -0.555570233f, -0.608761429f, -0.659345815f, -0.707106781f, -0.751839807f, -0.79335334f, -0.831469612f,
+            -0.866025404f, -0.896872742f, -0.923879533f, -0.946930129f, -0.965925826f, -0.98078528f, -0.991444861f, -0.997858923f,
+            -1.f, -0.997858923f, -0.991444861f, -0.98078528f, -0.965925826f, -0.946930129f, -0.923879533f, -0.896872742f,
+            -0.866025404f, -0.831469612f, -0.79335334f, -0.751839807f, -0.707106781f, -0.659345815f, -0.608761429f, -0.555570233f,
+            -0.5f, -0.44228869f, -0.382683432f, -0.321439465f, -0.258819045f, -0.195090322f, -0.130526192f, -0.0654031292f,
+            0.f, 0.0654031292f, 0.130526192f, 0.195090322f, 0.258819045f, 0.321439465f, 0.382683432f, 0.44228869f,
+            0.5f, 0.555570233f, 0.608761429f, 0.659345815f, 0.707106781f, 0.751839807f, 0.79335334f, 0.831469612f,
+            0.866025404f, 0.896872742f, 0.923879533f, 0.946930129f, 0.965925826f, 0.98078528f, 0.991444861f, 0.997858923f};
+    constexpr float ks[96] = {
+            0.f, -0.0654031292f, -0.130526192f, -0.195090322f, -0.258819045f, -0.321439465f, -0.382683432f, -0.44228869f,
+            -0.5f, -0.555570233f, -0.608761429f, -0.659345815f, -0.707106781f, -0.751839807f, -0.79335334f, -0.831469612f,
+            -0.866025404f, -0.896872742f, -0.923879533f, -0.946930129f, -0.965925826f, -0.98078528f, -0.991444861f, -0.997858923f,
+            -1.f, -0.997858923f, -0.991444861f, -0.98078528f, -0.965925826f, -0.946930129f, -0.923879533f, -0.896872742f,
+            -0.866025404f, -0.831469612f, -0.79335334f, -0.751839807f, -0.707106781f, -0.659345815f, -0.608761429f, -0.555570233f,
+            -0.5f, -0.44228869f, -0.382683432f, -0.321439465f, -0.258819045f, -0.195090322f, -0.130526192f, -0.0654031292f,
+            0.f, 0.0654031292f, 0.130526192f, 0.195090322f, 0.258819045f, 0.321439465f, 0.382683432f, 0.44228869f,
+            0.5f, 0.555570233f, 0.608761429f, 0.659345815f, 0.707106781f, 0.751839807f, 0.79335334f, 0.831469612f,
+            0.866025404f, 0.896872742f, 0.923879533f, 0.946930129f, 0.965925826f, 0.98078528f, 0.991444861f, 0.997858923f,
+            1.f, 0.997858923f, 0.991444861f, 0.98078528f, 0.965925826f, 0.946930129f, 0.923879533f, 0.896872742f,
+            0.866025404f, 0.831469612f, 0.79335334f, 0.751839807f, 0.707106781f, 0.659345815f, 0.608761429f, 0.555570233f,
+            0.5f, 0.44228869f, 0.382683432f, 0.321439465f, 0.258819045f, 0.195090322f, 0.130526192f, 0.0654031292f};
+    return make_float2(kc[j], ks[j]);
+}
+
+template <int N> struct Dft {      // in-place forward DFT of v[0..N), natural order in and out; N = 2^a * {1,3}
+    static __device__ __forceinline__ void run(float2 (&v)[N]) {
+        static_assert(N % 2 == 0 && 96 % N == 0, "radix-2 split over the 96-entry table");
+        float2 e[N / 2], o[N / 2];
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+        Dft<N / 2>::run(e);
+        Dft<N / 2>::run(o);
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+            const float2 t = (k == 0) ? o[0] : cmul(o[k], tw96(k * (96 / N)));
+            v[k] = make_float2(e[k].x + t.x, e[k].y + t.y);
+            v[k + N / 2] = make_float2(e[k].x - t.x, e[k].y - t.y);
+        }
+    }
+};
+template <> struct Dft<1> { static __device__ __forceinline__ void run(float2 (&)[1]) {} };
+template <> struct Dft<3> {
+    static __device__ __forceinline__ void run(float2 (&v)[3]) {
+        const float h = 0.8660254037844386f;
+        const float2 a = v[0], s = make_float2(v[1].x + v[2].x, v[1].y + v[2].y), d = make_float2(v[1].x - v[2].x, v[1].y - v[2].y);
+        const float2 m = make_float2(a.x - 0.5f * s.x, a.y - 0.5f * s.y);
+        v[0] = make_float2(a.x + s.x, a.y + s.y);
+        v[1] = make_float2(m.x + h * d.y, m.y - h * d.x);
+        v[2] = make_float2(m.x - h * d.y, m.y + h * d.x);
+    }
+};
+
+constexpr int two_nt(int n1, int n2) { return kCB * (n1 > n2 ? n1 : n2); }
+
+template <int N1, int N2> struct TwoStep {
+    static constexpr int N = N1 * N2;
+    static constexpr int NMAX = N1 > N2 ? N1 : N2;
+    static constexpr int NT = kCB * NMAX;                       // threads per workgroup
+    static constexpr int PITCH = N2 * kCB + kCB;                // float2 per exchange row (+128 B: rows alternate bank halves)
+    static constexpr int PITCH_T = N1 * kCB + kCB;              // the transposed (inverse) exchange
+    static constexpr int LDS = (N1 * PITCH > N2 * PITCH_T ? N1 * PITCH : N2 * PITCH_T) * (int)sizeof(float2);
+};
+
+// a[n1] = x[n1*N2 + sub] held by thread (ch, sub < N2)  ->  b[k2] = X[sub + N1*k2] held by thread (ch, sub < N1)
+template <int N1, int N2>
+__device__ __forceinline__ void two_step(float2 (&a)[N1], float2 (&b)[N2], float2* lds, const float2* __restrict__ tw, int ch, int sub) {
+    constexpr int PITCH = N2 * kCB + kCB;
+    if (sub < N2) {
+        Dft<N1>::run(a);
+#pragma unroll
+        for (int k1 = 0; k1 < N1; ++k1) lds[k1 * PITCH + sub * kCB + ch] = k1 == 0 ? a[0] : cmul(a[k1], tw[sub * k1]);
+    }
+    __syncthreads();
+    if (sub < N1) {
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2) b[n2] = lds[sub * PITCH + n2 * kCB + ch];
+        Dft<N2>::run(b);
+    }
+}
+
+// workgroup id -> (line, channel group): the channel groups of one line are consecutive on one XCD
+__device__ __forceinline__ bool decode_wg(int nlines, int ncg, int& line, int& cg) {
+    const int wg = blockIdx.x, xcd = wg & 7, i = wg >> 3;
+    cg = i % ncg;
+    line = (i / ncg) * 8 + xcd;
+    return line < nlines;
+}
+
+template <typename T, int N1, int N2>
+__global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_fwd_kernel(FftP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lds = reinterpret_cast<float2*>(smem);
+    const int ch = threadIdx.x % kCB, sub = threadIdx.x / kCB;
+    int line, cg;
+    if (!decode_wg(p.B * p.H, p.C / kCB, line, cg)) return;
+    const size_t C = p.C;
+    float2 a[N1], b[N2];
+    if (sub < N2) {
+        const T* src = reinterpret_cast<const T*>(p.x) + (size_t)line * p.W * C + cg * kCB + ch;
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) a[n1] = make_float2(to_f(src[(size_t)(n1 * N2 + sub) * C]), 0.f);
+    }
+    two_step<N1, N2>(a, b, lds, p.tw, ch, sub);
+    if (sub < N1) {
+        float2* dst = p.S + (size_t)line * p.Wh * C + cg * kCB + ch;
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) {
+            const int kw = sub + N1 * k2;
+            if (kw < p.Wh) dst[(size_t)kw * C] = b[k2];
+        }
+    }
+}
+
+template <typename T, int N1, int N2>
+__global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_inv_kernel(FftP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lds = reinterpret_cast<float2*>(smem);
+    float2* stage = lds + TwoStep<N1, N2>::LDS / (int)sizeof(float2);     // [Wh][16 channels]: the half spectrum of this line
+    const int ch = threadIdx.x % kCB, sub = threadIdx.x / kCB;
+    int line, cg;
+    if (!decode_wg(p.B * p.H, p.C / kCB, line, cg)) return;
+    const size_t C = p.C;
+    constexpr int N = N1 * N2, WH = N / 2 + 1, NSUB = two_nt(N1, N2) / kCB;
+    // the half spectrum is fetched once; the mirrored half of the Hermitian extension comes out of LDS
+    {
+        const float2* src = p.S3 + (size_t)line * WH * C + cg * kCB + ch;
+#pragma unroll
+        for (int i = 0; i < (WH + NSUB - 1) / NSUB; ++i) {
+            const int k = sub + i * NSUB;
+            if (k < WH) stage[k * kCB + ch] = src[(size_t)k * C];
+        }
+    }
+    __syncthreads();
+    float2 a[N1], b[N2];
+    if (sub < N2) {
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const int k = n1 * N2 + sub;
+            float2 v;
+            if (k < WH) { v = stage[k * kCB + ch]; v.y = -v.y; }       // conj(F[k])
+            else v = stage[(N - k) * kCB + ch];                          // conj(conj(F[N-k]))
+            a[n1] = v;
+        }
+    }
+    two_step<N1, N2>(a, b, lds, p.tw, ch, sub);
+    if (sub < N1) {
+        T* dst = reinterpret_cast<T*>(p.y) + (size_t)line * p.W * C + cg * kCB + ch;
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) dst[(size_t)(sub + N1 * k2) * C] = from_f<T>(b[k2].x * p.scale);
+    }
+}
+
+template <int N1, int N2>
+__global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lds = reinterpret_cast<float2*>(smem);
+    const int ch = threadIdx.x % kCB, sub = threadIdx.x / kCB;
+    int line, cg;
+    if (!decode_wg(p.B * p.Wh, p.C / kCB, line, cg)) return;
+    const int b = line / p.Wh, kw = line - b * p.Wh;
+    const size_t C = p.C, hs = (size_t)p.Wh * C;
+    const size_t off = ((size_t)b * p.H * p.Wh + kw) * C + cg * kCB + ch;
+    float2 a[N1], F[N2];
+    if (sub < N2) {
+        const float2* own = p.S + off;
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) a[n1] = own[(size_t)(n1 * N2 + sub) * hs];
+    }
+    two_step<N1, N2>(a, F, lds, p.tw, ch, sub);            // F[k2] = spectrum at kh = sub + N1*k2 (threads sub < N1)
+    // does the band touch this column at all?  low band: only kw <= radius; high band: everywhere
+    const bool want_partner = !p.load_ratio && (p.high != 0 || (float)(kw * kw) <= p.radius2);
+    float rr[N2];
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) rr[k2] = 1.f;
+    if (want_partner) {                                    // workgroup-uniform
+        float2 G[N2];
+        __syncthreads();                                   // step B of the own column has left the exchange buffer
+        if (sub < N2) {
+            const int64_t pb = p.perm ? p.perm[b] : b;
+            const float2* par = p.S + ((size_t)pb * p.H * p.Wh + kw) * C + cg * kCB + ch;
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) a[n1] = par[(size_t)(n1 * N2 + sub) * hs];
+        }
+        two_step<N1, N2>(a, G, lds, p.tw, ch, sub);
+        if (sub < N1) {
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) {
+                const int kh = sub + N1 * k2;
+                const int dh = kh < p.H - kh ? kh : p.H - kh;
+                const bool band = (float)(dh * dh + kw * kw) <= p.radius2;
+                if (band != (p.high != 0)) {
+                    const float am = sqrtf(F[k2].x * F[k2].x + F[k2].y * F[k2].y);
+                    const float a2 = sqrtf(G[k2].x * G[k2].x + G[k2].y * G[k2].y);
+                    if (am > 1e-20f) rr[k2] = ((1.f - p.lam) * am + p.lam * a2) / am;
+                }
+            }
+        }
+    }
+    if (sub < N1) {
+        float* rat = p.ratio ? p.ratio + off : nullptr;
+        if (p.load_ratio) {
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) rr[k2] = rat[(size_t)(sub + N1 * k2) * hs];
+        } else if (rat) {
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) rat[(size_t)(sub + N1 * k2) * hs] = rr[k2];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) F[k2] = make_float2(F[k2].x * rr[k2], -F[k2].y * rr[k2]);   // conj for the inverse
+    }
+    // inverse along H: the register layout (thread k1 owns k = N1*k2 + k1) is the INPUT layout of the transposed
+    // two-step transform, so it starts without an exchange
+    __syncthreads();
+    float2 y[N1];
+    two_step<N2, N1>(F, y, lds, p.tw, ch, sub);            // y[j] = value at h = sub + N2*j (threads sub < N2)
+    if (sub < N2) {
+        float2* dst = p.S3 + off;
+#pragma unroll
+        for (int j = 0; j < N1; ++j) dst[(size_t)(sub + N2 * j) * hs] = make_float2(y[j].x, -y[j].y);
+    }
+}
+
+template <typename K>
+static int launch_two(K kern, const FftP& p, int nlines, int nt, int lds, hipStream_t st) {
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const unsigned grid = (unsigned)(((nlines + 7) / 8) * 8 * (p.C / kCB));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((unsigned)nt), lds, st, p);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+// pass: 0 rows forward, 1 columns + mix, 2 rows inverse
+template <typename T, int N1, int N2>
+static int launch_fast_pass(FftP p, int pass, const float2* tw, hipStream_t st) {
+    using TS = TwoStep<N1, N2>;
+    p.N = TS::N;
+    p.tw = tw;
+    if (pass == 0) return launch_two(fft_rows_fwd_kernel<T, N1, N2>, p, p.B * p.H, TS::NT, TS::LDS, st);
+    if (pass == 1) return launch_two(fft_cols_mix_kernel<N1, N2>, p, p.B * p.Wh, TS::NT, TS::LDS, st);
+    return launch_two(fft_rows_inv_kernel<T, N1, N2>, p, p.B * p.H, TS::NT, TS::LDS + (TS::N / 2 + 1) * kCB * (int)sizeof(float2), st);
+}
+
+template <typename T>
+static int fast_pass(const FftP& p, int n, int pass, const float2* tw, hipStream_t st) {
+    switch (n) {
+        case 32: return launch_fast_pass<T, 2, 16>(p, pass, tw, st);
+        case 48: return launch_fast_pass<T, 3, 16>(p, pass, tw, st);
+        case 64: return launch_fast_pass<T, 4, 16>(p, pass, tw, st);
+        case 96: return launch_fast_pass<T, 6, 16>(p, pass, tw, st);
+        case 128: return launch_fast_pass<T, 8, 16>(p, pass, tw, st);
+        case 192: return launch_fast_pass<T, 12, 16>(p, pass, tw, st);
+        case 256: return launch_fast_pass<T, 16, 16>(p, pass, tw, st);
+        case 384: return launch_fast_pass<T, 12, 32>(p, pass, tw, st);
+        case 512: return launch_fast_pass<T, 16, 32>(p, pass, tw, st);
+    }
+    set_error("fourier_mix: no two-step plan for length %d", n);
+    return -1;
+}
+static bool has_fast_plan(int n) {
+    return n == 32 || n == 48 || n == 64 || n == 96 || n == 128 || n == 192 || n == 256 || n == 384 || n == 512;
+}
+
 template <typename T>
 static int run_mix(FftP p, const float2* twH, const float2* twW, hipStream_t st) {
+    static int generic = -1;
+    if (generic < 0) { const char* e = getenv("MRFP_FFT_GENERIC"); generic = e ? atoi(e) : 0; }
+    if (!generic && has_fast_plan(p.H) && has_fast_plan(p.W)) {
+        int rc;
+        if ((rc = fast_pass<T>(p, p.W, 0, twW, st))) return rc;
+        if ((rc = fast_pass<T>(p, p.H, 1, twH, st))) return rc;
+        return fast_pass<T>(p, p.W, 2, twW, st);
+    }
     int rc;
     if ((rc = launch_pass<T, 0>(p, p.W, twW, p.B * p.H, st))) return rc;
     if ((rc = launch_pass<T, 1>(p, p.H, twH, p.B * p.Wh, st))) return rc;

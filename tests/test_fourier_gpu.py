@@ -17,7 +17,11 @@ def relerr(a, b):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape,radius,lam,high", [((2, 16, 8, 8), 2.0, 1.0, False), ((3, 32, 48, 64), 6.0, 1.0, False),
                                                    ((2, 64, 64, 64), 16.0, 0.5, True), ((2, 16, 96, 192), 16.0, 1.0, False),
-                                                   ((4, 16, 12, 18), 3.0, 0.7, True)])
+                                                   ((4, 16, 12, 18), 3.0, 0.7, True),
+                                                   # two-step register path: every planned line length
+                                                   ((2, 16, 192, 192), 16.0, 1.0, False), ((2, 32, 128, 256), 20.0, 0.6, True),
+                                                   ((1, 16, 384, 512), 16.0, 1.0, False), ((2, 16, 32, 48), 5.0, 1.0, True),
+                                                   ((3, 16, 256, 64), 16.0, 0.3, True)])
 def test_fourier_amplitude_mix(dtype, shape, radius, lam, high):
     from mrfp_amd import ops
     B, C, H, W = shape
