@@ -92,8 +92,42 @@ __device__ __forceinline__ uint4 bload(const __amdgpu_buffer_rsrc_t& r, unsigned
 // DMA: tiles go global -> LDS directly (buffer_load ... lds, no staging registers, no ds_write traffic); the LDS
 //      image of one wave-instruction is lane-linear (base + lane*16), so the XOR swizzle is applied to the SOURCE
 //      chunk each lane fetches; needs NBUF == 2 (the DMA of tile k+1 lands while tile k is multiplied).
+// element access into a 16-byte chunk with COMPILE-TIME indices (keeps the chunk in registers)
+template <typename T> __device__ __forceinline__ T chunk_get(const uint4& v, int u);
+template <> __device__ __forceinline__ float chunk_get<float>(const uint4& v, int u) {
+    const unsigned w = u == 0 ? v.x : u == 1 ? v.y : u == 2 ? v.z : v.w;
+    return __uint_as_float(w);
+}
+template <> __device__ __forceinline__ bf16 chunk_get<bf16>(const uint4& v, int u) {
+    const unsigned w = (u >> 1) == 0 ? v.x : (u >> 1) == 1 ? v.y : (u >> 1) == 2 ? v.z : v.w;
+    const unsigned short h = (unsigned short)((u & 1) ? (w >> 16) : (w & 0xffffu));
+    bf16 r;
+    __builtin_memcpy(&r, &h, 2);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void chunk_set(uint4& v, int u, T x);
+template <> __device__ __forceinline__ void chunk_set<float>(uint4& v, int u, float x) {
+    const unsigned w = __float_as_uint(x);
+    if (u == 0) v.x = w; else if (u == 1) v.y = w; else if (u == 2) v.z = w; else v.w = w;
+}
+template <> __device__ __forceinline__ void chunk_set<bf16>(uint4& v, int u, bf16 x) {
+    unsigned short h;
+    __builtin_memcpy(&h, &x, 2);
+    const unsigned sh = (u & 1) ? 16u : 0u, mask = ~(0xffffu << sh), bits = (unsigned)h << sh;
+    if ((u >> 1) == 0) v.x = (v.x & mask) | bits;
+    else if ((u >> 1) == 1) v.y = (v.y & mask) | bits;
+    else if ((u >> 1) == 2) v.z = (v.z & mask) | bits;
+    else v.w = (v.w & mask) | bits;
+}
+template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a, const uint4& b) {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int u = 0; u < 16 / (int)sizeof(T); ++u) chunk_set<T>(r, u, from_f<T>(to_f(chunk_get<T>(a, u)) + to_f(chunk_get<T>(b, u))));
+    return r;
+}
+
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
-__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 1)) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     static_assert(!DMA || NBUF == 2, "LDS-DMA staging needs two LDS buffers");
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
@@ -148,7 +182,6 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 1)) void conv_ige
         tr = rs / p.S;
         ts = rs - tr * p.S;
     }
-    const int tiles_per_tap = p.cpr >> 3;
 
     typedef __attribute__((address_space(3))) void lds_void;
     auto load_tile = [&](int kt, uint4 (&ra)[SA], uint4 (&rb)[SB], int dbuf) {
@@ -319,23 +352,27 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 1)) void conv_ige
             if (m < p.M && n < p.N) {
                 uint4 v = *reinterpret_cast<const uint4*>(ep + row * EPITCH + ch * 16);
                 T* dst = y + (size_t)m * p.ldy + n;
+                const bool full = n + EPC <= p.N;
+                // (everything below indexes the chunk with compile-time constants only: a run-time index would
+                //  push `v` into scratch memory)
                 if (p.addend) {      // y += addend (the skip-connection gradient): one 16-byte read instead of a separate add pass
                     const T* ad = reinterpret_cast<const T*>(p.addend) + (size_t)m * p.ldy + n;
-                    T* tv = reinterpret_cast<T*>(&v);
-                    if (n + EPC <= p.N) {
-                        const uint4 av = *reinterpret_cast<const uint4*>(ad);
-                        const T* ta = reinterpret_cast<const T*>(&av);
-#pragma unroll
-                        for (int u = 0; u < EPC; ++u) tv[u] = from_f<T>(to_f(tv[u]) + to_f(ta[u]));
+                    uint4 av = make_uint4(0u, 0u, 0u, 0u);
+                    if (full) {
+                        av = *reinterpret_cast<const uint4*>(ad);
                     } else {
-                        for (int u = 0; u < EPC && n + u < p.N; ++u) tv[u] = from_f<T>(to_f(tv[u]) + to_f(ad[u]));
+#pragma unroll
+                        for (int u = 0; u < EPC; ++u)
+                            if (n + u < p.N) chunk_set<T>(av, u, ad[u]);
                     }
+                    v = chunk_add<T>(v, av);
                 }
-                if (n + EPC <= p.N) {
+                if (full) {
                     *reinterpret_cast<uint4*>(dst) = v;
                 } else {
-                    const T* src = reinterpret_cast<const T*>(&v);
-                    for (int u = 0; u < EPC && n + u < p.N; ++u) dst[u] = src[u];
+#pragma unroll
+                    for (int u = 0; u < EPC; ++u)
+                        if (n + u < p.N) dst[u] = chunk_get<T>(v, u);
                 }
             }
         }
@@ -431,10 +468,26 @@ static bool use_big_tile(const ConvP& p, int esz) {
     const int nkt = (p.kchunks + 7) >> 3;
     return p.N >= 192 && n256 * 256 - p.N <= 64 && nkt >= 18 && m256 * n256 >= 448;
 }
+// 96x128 tile (4 waves x 96x32): same K loop, 3/4 of the rows.  Chosen when the 128-row tiling leaves the last
+// round of workgroups (3 per CU x 256 CUs) mostly empty: M = 36 864 (16 x 48 x 48), N = 256 is 576 tiles = 0.75 rounds
+// at 128 rows but exactly one full round (768) at 96 rows.
+static int g_t96 = -1;
+static bool use_tile96(const ConvP& p, int esz) {
+    if (g_t96 < 0) {
+        const char* e = getenv("MRFP_CONV_T96");
+        g_t96 = e ? atoi(e) : 1;
+    }
+    if (!g_t96 || p.N <= 64 || use_big_tile(p, esz)) return false;
+    const int64_t n128 = (p.N + 127) / 128, slots = 768;
+    const int64_t t128 = ((p.M + 127) / 128) * n128, t96 = ((p.M + 95) / 96) * n128;
+    const int64_t c128 = ((t128 + slots - 1) / slots) * 128, c96 = ((t96 + slots - 1) / slots) * 96;
+    return c96 * 10 <= c128 * 9;       // at least 10 % fewer row-rounds
+}
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
 static int64_t stats_row_blocks(const ConvP& p, int esz) {
     if (p.N <= 64) return (int64_t)((p.M + 255) / 256) * 4;          // <4,1,2,2>: 256-row tile, 4 wave rows
     if (use_big_tile(p, esz)) return (int64_t)((p.M + 255) / 256) * 2;  // <2,4,4,2>: 256-row tile, 2 wave rows
+    if (use_tile96(p, esz)) return (int64_t)((p.M + 95) / 96);          // <1,4,3,1>: 96-row tile, 1 wave row
     return (int64_t)((p.M + 127) / 128) * 2;                          // <2,2,2,2>: 128-row tile, 2 wave rows
 }
 
@@ -447,6 +500,7 @@ static int run_igemm(const ConvP& p, hipStream_t st) {
     // layers (fill / drain dominate) and on N that wastes most of the second 256-column tile; a 256x128
     // 4-wave variant (254 VGPRs) lost 25 % everywhere and was dropped.
     if (use_big_tile(p, (int)sizeof(T))) return pick_igemm<T, 2, 4, 4, 2>(p, st);
+    if (use_tile96(p, (int)sizeof(T))) return pick_igemm<T, 1, 4, 3, 1>(p, st);
     return pick_igemm<T, 2, 2, 2, 2>(p, st);
 }
 
