@@ -396,21 +396,29 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
 // Folds the per-row-block statistics [nblk][2][C] of a forward launch into kStatGroups rows (appended after row
 // nblk) so that the BatchNorm finalize kernel walks 64 partials per channel instead of thousands.
 constexpr int kStatGroups = 64;
-__global__ void compact_stats_kernel(float* __restrict__ st, int nblk, int C2) {   // C2 = 2*C floats per row
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
-    if (c >= C2) return;
+__global__ __launch_bounds__(256) void compact_stats_kernel(float* __restrict__ st, int nblk, int C2) {   // C2 = 2*C floats per row
+    // block = 64 columns x 4 row quarters (fixed split and fixed order: bitwise reproducible)
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx, g = blockIdx.y;
     const int per = (nblk + kStatGroups - 1) / kStatGroups;
     const int r0 = g * per, r1 = min(nblk, r0 + per);
+    const int q = (r1 - r0 + 3) / 4;
+    const int a = min(r1, r0 + ty * q), b = min(r1, a + q);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int r = r0;
-    for (; r + 3 < r1; r += 4) {
-        a0 += st[(size_t)r * C2 + c];
-        a1 += st[(size_t)(r + 1) * C2 + c];
-        a2 += st[(size_t)(r + 2) * C2 + c];
-        a3 += st[(size_t)(r + 3) * C2 + c];
+    if (c < C2) {
+        int r = a;
+        for (; r + 3 < b; r += 4) {
+            a0 += st[(size_t)r * C2 + c];
+            a1 += st[(size_t)(r + 1) * C2 + c];
+            a2 += st[(size_t)(r + 2) * C2 + c];
+            a3 += st[(size_t)(r + 3) * C2 + c];
+        }
+        for (; r < b; ++r) a0 += st[(size_t)r * C2 + c];
     }
-    for (; r < r1; ++r) a0 += st[(size_t)r * C2 + c];
-    st[(size_t)(nblk + g) * C2 + c] = (a0 + a1) + (a2 + a3);
+    part[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && c < C2) st[(size_t)(nblk + g) * C2 + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
 }
 
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
@@ -589,7 +597,7 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
     const int64_t nblk = stats_row_blocks(p, esz);
     if (nblk > 2 * kStatGroups) {
         const int C2 = 2 * (int)ldy;
-        hipLaunchKernelGGL(compact_stats_kernel, dim3((unsigned)((C2 + 255) / 256), kStatGroups), dim3(256), 0,
+        hipLaunchKernelGGL(compact_stats_kernel, dim3((unsigned)((C2 + 63) / 64), kStatGroups), dim3(256), 0,
                            (hipStream_t)stream, colstats, (int)nblk, C2);
         MRFP_LAUNCH_CHECK();
     }
@@ -863,19 +871,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
 }
 
 // dW[n][c][r][s] (OIHW fp32, c < Ctrue) = sum_z slab[z][n][(r*S+s)*C + c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int N, int Q, int C, int Ctrue, int R,
-                                    int S, float* __restrict__ dw) {
-    const int64_t total = (int64_t)N * Ctrue * R * S;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int s = (int)(i % S);
-        int64_t rest = i / S;
-        const int r = (int)(rest % R); rest /= R;
-        const int c = (int)(rest % Ctrue);
-        const int n = (int)(rest / Ctrue);
-        const size_t src = (size_t)n * Q + (size_t)(r * S + s) * C + c;
-        float acc = 0.f;
-        for (int z = 0; z < splits; ++z) acc += slab[(size_t)z * N * Q + src];
-        dw[i] = acc;
+// Threads walk the SLAB order (4 consecutive channels each, 16-byte loads: the slabs are ~20x the size of dW, so
+// their reads are the ones that must coalesce); the OIHW stores are 4-byte scattered but few.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int N, int Q, int C, int Ctrue, int RS,
+                                    float* __restrict__ dw) {
+    const int64_t total4 = (int64_t)N * Q / 4, NQ = (int64_t)N * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = i * 4;
+        const int n = (int)(j / Q), q = (int)(j - (int64_t)n * Q);
+        const int rs = q / C, c = q - rs * C;
+        if (c >= Ctrue) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int z = 0; z < splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)z * NQ + j);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float* d = dw + ((size_t)n * Ctrue + c) * RS + rs;
+        d[0] = acc.x;
+        if (c + 1 < Ctrue) d[RS] = acc.y;
+        if (c + 2 < Ctrue) d[2 * RS] = acc.z;
+        if (c + 3 < Ctrue) d[3 * RS] = acc.w;
     }
 }
 
@@ -954,11 +970,11 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
     if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st) : launch_wgrad<float, 2, 2>(p, splits, st);
     else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st) : launch_wgrad<bf16, 2, 2>(p, splits, st);
     if (rc) return rc;
-    const int64_t total = N * Ctrue * R * S;
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    const int64_t total4 = N * (int64_t)p.Q / 4;          // Q = R*S*C and C*esz % 16 == 0  =>  Q % 4 == 0
+    int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, splits, (int)N,
-                       p.Q, (int)C, (int)Ctrue, (int)R, (int)S, dw);
+                       p.Q, (int)C, (int)Ctrue, (int)(R * S), dw);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
