@@ -486,9 +486,17 @@ static bool use_tile96(const ConvP& p, int esz) {
         g_t96 = e ? atoi(e) : 1;
     }
     if (!g_t96 || p.N <= 64 || use_big_tile(p, esz)) return false;
-    const int64_t n128 = (p.N + 127) / 128, slots = 768;
+    if (g_t96 == 2) return true;      // A/B measurements: 96-row tile wherever it is legal
+    // rounds of resident workgroups: 3 per CU for the 128x128 tile (144-148 registers), 4 per CU for the 96x128 tile
+    // (<= 120).  Measured in the bench workload (bench.py --dump-convs, MRFP_CONV_T96=0/1/2): the 96-row tile wins
+    // when everything fits one round (M = 36 864 layers: +7..35 %) and on short-K (memory-bound) layers; long-K
+    // layers with many rounds keep the 128x128 tile (higher FLOP per LDS byte).
+    const int64_t n128 = (p.N + 127) / 128;
     const int64_t t128 = ((p.M + 127) / 128) * n128, t96 = ((p.M + 95) / 96) * n128;
-    const int64_t c128 = ((t128 + slots - 1) / slots) * 128, c96 = ((t96 + slots - 1) / slots) * 96;
+    const int nkt = (p.kchunks + 7) >> 3;
+    if (t96 <= 1024) return true;
+    if (nkt > 8) return false;
+    const int64_t c128 = ((t128 + 767) / 768) * 128, c96 = ((t96 + 1023) / 1024) * 96;
     return c96 * 10 <= c128 * 9;       // at least 10 % fewer row-rounds
 }
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
