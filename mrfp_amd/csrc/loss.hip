@@ -185,9 +185,12 @@ namespace mrfp {
 
 __device__ __forceinline__ float up_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
-template <typename T>
+// CP = class count rounded up to a multiple of 8 (compile time): every loop over classes is fully unrolled with a
+// `c < C` predicate, so the per-pixel class vector lives in registers (a run-time bound puts it in scratch memory:
+// measured 469 / 1060 us per call at 16x768x768x19 before, see profiles/).
+template <typename T, int CP>
 __device__ __forceinline__ void up_logits(const T* __restrict__ P, int ld, int Hi, int Wi, int H, int W, int C, int b,
-                                          int oh, int ow, float (&z)[kMaxClasses]) {
+                                          int oh, int ow, float (&z)[CP]) {
     const float sh = up_scale(Hi, H), sw = up_scale(Wi, W);
     const float fh = sh * (float)oh, fw = sw * (float)ow;
     const int h0 = (int)fh, w0 = (int)fw;
@@ -198,19 +201,23 @@ __device__ __forceinline__ void up_logits(const T* __restrict__ P, int ld, int H
     const T* p10 = P + (((size_t)b * Hi + h1) * Wi + w0) * ld;
     const T* p11 = P + (((size_t)b * Hi + h1) * Wi + w1) * ld;
     constexpr int EPC = 16 / (int)sizeof(T);
-    for (int c0 = 0; c0 < C; c0 += EPC) {
-        float a[EPC], bb[EPC], c[EPC], d[EPC];
-        load_f<T, EPC>(p00 + c0, a);
-        load_f<T, EPC>(p01 + c0, bb);
-        load_f<T, EPC>(p10 + c0, c);
-        load_f<T, EPC>(p11 + c0, d);
 #pragma unroll
-        for (int i = 0; i < EPC; ++i)
-            if (c0 + i < C) z[c0 + i] = lh0 * (lw0 * a[i] + lw1 * bb[i]) + lh1 * (lw0 * c[i] + lw1 * d[i]);
+    for (int c0 = 0; c0 < CP; c0 += EPC) {
+        float a[EPC], bb[EPC], c[EPC], d[EPC];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) { a[i] = 0.f; bb[i] = 0.f; c[i] = 0.f; d[i] = 0.f; }
+        if (c0 < C) {        // chunks past the class count are never read (the pitch may be shorter than CP)
+            load_f<T, EPC>(p00 + c0, a);
+            load_f<T, EPC>(p01 + c0, bb);
+            load_f<T, EPC>(p10 + c0, c);
+            load_f<T, EPC>(p11 + c0, d);
+        }
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) z[c0 + i] = lh0 * (lw0 * a[i] + lw1 * bb[i]) + lh1 * (lw0 * c[i] + lw1 * d[i]);
     }
 }
 
-template <typename T>
+template <typename T, int CP>
 __global__ __launch_bounds__(kCeThreads) void upsample_ce_fwd_kernel(const T* __restrict__ P, int ld, const int64_t* __restrict__ target,
                                                                      int B, int Hi, int Wi, int H, int W, int C, int64_t ignore,
                                                                      float* __restrict__ ws) {
@@ -222,12 +229,15 @@ __global__ __launch_bounds__(kCeThreads) void upsample_ce_fwd_kernel(const T* __
         if (tg == ignore || tg < 0 || tg >= C) continue;
         const int b = (int)(p / ((int64_t)H * W)), rem = (int)(p - (int64_t)b * H * W);
         const int oh = rem / W, ow = rem - oh * W;
-        float z[kMaxClasses];
-        up_logits<T>(P, ld, Hi, Wi, H, W, C, b, oh, ow, z);
+        float z[CP];
+        up_logits<T, CP>(P, ld, Hi, Wi, H, W, C, b, oh, ow, z);
         float m = -INFINITY;
-        for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+#pragma unroll
+        for (int c = 0; c < CP; ++c) if (c < C) m = fmaxf(m, z[c]);
         float s = 0.f, zt = 0.f;
-        for (int c = 0; c < C; ++c) { s += __expf(z[c] - m); zt = (c == (int)tg) ? z[c] : zt; }
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) { s += __expf(z[c] - m); zt = (c == (int)tg) ? z[c] : zt; }
         nll += (m + __logf(s)) - zt;
         cnt += 1.f;
     }
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(kCeThreads) void upsample_ce_fwd_kernel(const T* __
     }
 }
 
-template <typename T>
+template <typename T, int CP>
 __global__ __launch_bounds__(kCeThreads) void upsample_ce_bwd_kernel(const T* __restrict__ P, int ld, const int64_t* __restrict__ target,
                                                                      const float* __restrict__ loss, const float* __restrict__ gscale,
                                                                      T* __restrict__ dlogits, int Cd, int B, int Hi, int Wi, int H,
@@ -255,25 +265,61 @@ __global__ __launch_bounds__(kCeThreads) void upsample_ce_bwd_kernel(const T* __
     for (int64_t p = (int64_t)blockIdx.x * kCeThreads + threadIdx.x; p < npix; p += (int64_t)gridDim.x * kCeThreads) {
         const int64_t tg = target[p];
         T* d = dlogits + p * Cd;
-        float g[kMaxClasses];
+        float g[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) g[c] = 0.f;
         const bool valid = !(tg == ignore || tg < 0 || tg >= C);
         if (valid) {
             const int b = (int)(p / ((int64_t)H * W)), rem = (int)(p - (int64_t)b * H * W);
             const int oh = rem / W, ow = rem - oh * W;
-            up_logits<T>(P, ld, Hi, Wi, H, W, C, b, oh, ow, g);
+            up_logits<T, CP>(P, ld, Hi, Wi, H, W, C, b, oh, ow, g);
             float m = -INFINITY;
-            for (int c = 0; c < C; ++c) m = fmaxf(m, g[c]);
-            float s = 0.f;
-            for (int c = 0; c < C; ++c) { g[c] = __expf(g[c] - m); s += g[c]; }
-            const float inv = 1.f / s;
-            for (int c = 0; c < C; ++c) g[c] = (g[c] * inv - (c == (int)tg ? 1.f : 0.f)) * k;
-        }
-        for (int c0 = 0; c0 < Cd; c0 += EPC) {
-            float o[EPC];
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) o[i] = (valid && c0 + i < C) ? g[c0 + i] : 0.f;
-            store_f<T, EPC>(d + c0, o);
+            for (int c = 0; c < CP; ++c) if (c < C) m = fmaxf(m, g[c]);
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) { g[c] = c < C ? __expf(g[c] - m) : 0.f; s += g[c]; }
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) g[c] = c < C ? (g[c] * inv - (c == (int)tg ? 1.f : 0.f)) * k : 0.f;
         }
+#pragma unroll
+        for (int c0 = 0; c0 < CP; c0 += EPC) {
+            if (c0 < Cd) {
+                float o[EPC];
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) o[i] = g[c0 + i];
+                store_f<T, EPC>(d + c0, o);
+            }
+        }
+    }
+}
+
+// dispatch on CP = C rounded up to 8 (8 .. kMaxClasses)
+struct UpCeArgs {
+    const void* P; int ld; const int64_t* target; const float* loss; const float* gscale; void* dlogits; int Cd;
+    int B, Hi, Wi, H, W, C; int64_t ignore; float* ws; int nb; hipStream_t st;
+};
+template <typename T, int CP>
+static void launch_up_ce(const UpCeArgs& a, bool bwd) {
+    if (!bwd)
+        hipLaunchKernelGGL((upsample_ce_fwd_kernel<T, CP>), dim3(a.nb), dim3(kCeThreads), 0, a.st, (const T*)a.P, a.ld, a.target,
+                           a.B, a.Hi, a.Wi, a.H, a.W, a.C, a.ignore, a.ws);
+    else
+        hipLaunchKernelGGL((upsample_ce_bwd_kernel<T, CP>), dim3(a.nb), dim3(kCeThreads), 0, a.st, (const T*)a.P, a.ld, a.target,
+                           a.loss, a.gscale, (T*)a.dlogits, a.Cd, a.B, a.Hi, a.Wi, a.H, a.W, a.C, a.ignore);
+}
+template <typename T>
+static void dispatch_up_ce(const UpCeArgs& a, bool bwd) {
+    switch ((a.C + 7) / 8) {
+        case 1: launch_up_ce<T, 8>(a, bwd); break;
+        case 2: launch_up_ce<T, 16>(a, bwd); break;
+        case 3: launch_up_ce<T, 24>(a, bwd); break;
+        case 4: launch_up_ce<T, 32>(a, bwd); break;
+        case 5: launch_up_ce<T, 40>(a, bwd); break;
+        case 6: launch_up_ce<T, 48>(a, bwd); break;
+        case 7: launch_up_ce<T, 56>(a, bwd); break;
+        default: launch_up_ce<T, 64>(a, bwd); break;
     }
 }
 
@@ -291,12 +337,10 @@ int mrfp_upsample_ce_fwd(const void* P, int64_t ld, const int64_t* target, int d
                "upsample_ce_fwd: the score buffer must be channel-padded to 16-byte chunks (ld=%lld)", (long long)ld);
     hipStream_t st = (hipStream_t)stream;
     const int nb = mrfp::ce_blocks(B * H * W);
-    if (dtype == MRFP_F32)
-        hipLaunchKernelGGL((mrfp::upsample_ce_fwd_kernel<float>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const float*)P, (int)ld,
-                           target, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C, ignore_index, ws);
-    else
-        hipLaunchKernelGGL((mrfp::upsample_ce_fwd_kernel<mrfp::bf16>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const mrfp::bf16*)P,
-                           (int)ld, target, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C, ignore_index, ws);
+    mrfp::UpCeArgs a{P, (int)ld, target, nullptr, nullptr, nullptr, 0, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
+                     ignore_index, ws, nb, st};
+    if (dtype == MRFP_F32) mrfp::dispatch_up_ce<float>(a, false);
+    else mrfp::dispatch_up_ce<mrfp::bf16>(a, false);
     MRFP_LAUNCH_CHECK();
     hipLaunchKernelGGL(mrfp::ce_finalize_kernel, dim3(1), dim3(256), 0, st, ws, nb, loss);
     MRFP_LAUNCH_CHECK();
@@ -314,13 +358,10 @@ int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const
                "upsample_ce_bwd: channel pitches must be 16-byte multiples (ld=%lld Cd=%lld)", (long long)ld, (long long)Cd);
     hipStream_t st = (hipStream_t)stream;
     const int nb = mrfp::ce_blocks(B * H * W);
-    if (dtype == MRFP_F32)
-        hipLaunchKernelGGL((mrfp::upsample_ce_bwd_kernel<float>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const float*)P, (int)ld,
-                           target, loss, gscale, (float*)dlogits, (int)Cd, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C, ignore_index);
-    else
-        hipLaunchKernelGGL((mrfp::upsample_ce_bwd_kernel<mrfp::bf16>), dim3(nb), dim3(mrfp::kCeThreads), 0, st, (const mrfp::bf16*)P,
-                           (int)ld, target, loss, gscale, (mrfp::bf16*)dlogits, (int)Cd, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
-                           ignore_index);
+    mrfp::UpCeArgs a{P, (int)ld, target, loss, gscale, dlogits, (int)Cd, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
+                     ignore_index, nullptr, nb, st};
+    if (dtype == MRFP_F32) mrfp::dispatch_up_ce<float>(a, true);
+    else mrfp::dispatch_up_ce<mrfp::bf16>(a, true);
     MRFP_LAUNCH_CHECK();
     return 0;
 }

@@ -39,23 +39,42 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(const T* __restr
             const T* r0 = x + ((size_t)b * Hi + th.i0) * Wi * ldi + (size_t)cv * VEC;
             const T* r1 = x + ((size_t)b * Hi + th.i1) * Wi * ldi + (size_t)cv * VEC;
             const size_t dl = ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
-            for (int ow = trow; ow < Wo; ow += L.rowthreads) {
-                const Tap tw = ac_tap(sw, ow, Wi);
-                float a[VEC], bb[VEC], c[VEC], d[VEC], o[VEC];
-                load_f<T, VEC>(r0 + (size_t)tw.i0 * ldi, a);
-                load_f<T, VEC>(r0 + (size_t)tw.i1 * ldi, bb);
-                load_f<T, VEC>(r1 + (size_t)tw.i0 * ldi, c);
-                load_f<T, VEC>(r1 + (size_t)tw.i1 * ldi, d);
+            // 4 output pixels per trip, all 16-20 loads issued before the first use
+            for (int ow0 = trow; ow0 < Wo; ow0 += 4 * L.rowthreads) {
+                Tap tw[4];
+                VecT<T, VEC> ra[4], rb[4], rc[4], rd[4], re[4];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i)
-                    o[i] = th.l0 * (tw.l0 * a[i] + tw.l1 * bb[i]) + th.l1 * (tw.l0 * c[i] + tw.l1 * d[i]);
-                if (addend) {
-                    float e[VEC];
-                    load_f<T, VEC>(addend + dl + (size_t)ow * C, e);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) o[i] += e[i];
+                for (int u = 0; u < 4; ++u) {
+                    const int ow = ow0 + u * L.rowthreads;
+                    if (ow < Wo) {
+                        tw[u] = ac_tap(sw, ow, Wi);
+                        ra[u] = load_raw<T, VEC>(r0 + (size_t)tw[u].i0 * ldi);
+                        rb[u] = load_raw<T, VEC>(r0 + (size_t)tw[u].i1 * ldi);
+                        rc[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i0 * ldi);
+                        rd[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i1 * ldi);
+                        if (addend) re[u] = load_raw<T, VEC>(addend + dl + (size_t)ow * C);
+                    }
                 }
-                store_f<T, VEC>(y + dl + (size_t)ow * C, o);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ow = ow0 + u * L.rowthreads;
+                    if (ow >= Wo) continue;
+                    float a[VEC], bb[VEC], c[VEC], d[VEC], o[VEC];
+                    cvt_f<T, VEC>(ra[u], a);
+                    cvt_f<T, VEC>(rb[u], bb);
+                    cvt_f<T, VEC>(rc[u], c);
+                    cvt_f<T, VEC>(rd[u], d);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        o[i] = th.l0 * (tw[u].l0 * a[i] + tw[u].l1 * bb[i]) + th.l1 * (tw[u].l0 * c[i] + tw[u].l1 * d[i]);
+                    if (addend) {
+                        float e[VEC];
+                        cvt_f<T, VEC>(re[u], e);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) o[i] += e[i];
+                    }
+                    store_f<T, VEC>(y + dl + (size_t)ow * C, o);
+                }
             }
         }
     }
@@ -78,7 +97,10 @@ __device__ __forceinline__ void ac_range(int in, int out, int src, int& lo, int&
     if (hi > out - 1) hi = out - 1;
 }
 
-template <typename T, int VEC>
+// KW = compile-time bound on the number of destination columns that can touch one source column (0: unbounded,
+// plain nested loops).  With a bound the column weights are computed once per source pixel and the KW loads of a
+// destination row are issued together; the accumulation order (rows outer, columns inner) is the same in both forms.
+template <typename T, int VEC, int KW>
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
                                                                 int Hi, int Wi, int Ho, int Wo, int C, int ldi, int ly) {
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
@@ -97,17 +119,41 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restr
                 float acc[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-                for (int oh = oh0; oh <= oh1; ++oh) {
-                    const float wh = ac_weight(sh, oh, Hi, ih);
-                    if (wh == 0.f) continue;
-                    const T* dl = dy + ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
-                    for (int ow = ow0; ow <= ow1; ++ow) {
-                        const float w = wh * ac_weight(sw, ow, Wi, iw);
-                        if (w == 0.f) continue;
-                        float dv[VEC];
-                        load_f<T, VEC>(dl + (size_t)ow * C, dv);
+                if (KW > 0) {
+                    float ww[KW > 0 ? KW : 1];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) acc[i] += w * dv[i];
+                    for (int k = 0; k < KW; ++k) ww[k] = (ow0 + k <= ow1) ? ac_weight(sw, ow0 + k, Wi, iw) : 0.f;
+                    for (int oh = oh0; oh <= oh1; ++oh) {
+                        const float wh = ac_weight(sh, oh, Hi, ih);
+                        if (wh == 0.f) continue;
+                        const T* dl = dy + ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
+                        // unconditional loads from clamped (always valid) columns: no branch sits between them, so
+                        // all KW are in flight together; slots past the range carry weight 0 and are not added
+                        VecT<T, VEC> r[KW > 0 ? KW : 1];
+#pragma unroll
+                        for (int k = 0; k < KW; ++k) r[k] = load_raw<T, VEC>(dl + (size_t)min(ow0 + k, ow1) * C);
+#pragma unroll
+                        for (int k = 0; k < KW; ++k) {
+                            const float w = wh * ww[k];
+                            float dv[VEC];
+                            cvt_f<T, VEC>(r[k], dv);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) acc[i] += (ww[k] != 0.f) ? w * dv[i] : 0.f;
+                        }
+                    }
+                } else {
+                    for (int oh = oh0; oh <= oh1; ++oh) {
+                        const float wh = ac_weight(sh, oh, Hi, ih);
+                        if (wh == 0.f) continue;
+                        const T* dl = dy + ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
+                        for (int ow = ow0; ow <= ow1; ++ow) {
+                            const float w = wh * ac_weight(sw, ow, Wi, iw);
+                            if (w == 0.f) continue;
+                            float dv[VEC];
+                            load_f<T, VEC>(dl + (size_t)ow * C, dv);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) acc[i] += w * dv[i];
+                        }
                     }
                 }
                 store_f<T, VEC>(dx + (((size_t)b * Hi + ih) * Wi + iw) * ldi + (size_t)cv * VEC, acc);
@@ -220,8 +266,27 @@ static int do_bilinear_bwd(const void* dy, void* dx, int64_t B, int64_t Hi, int6
                            int64_t C, int64_t ldi, hipStream_t st) {
     const int ly = lines_per_image(B, Hi);
     const bool ok = aligned16(dy) && aligned16(dx) && ldi % FullVec<T>::value == 0;
-    DISPATCH_VEC(T, C, ok, bilinear_bwd_kernel, dim3((unsigned)(B * ly)), st, (const T*)dy, (T*)dx, (int)B, (int)Hi,
-                 (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly);
+    // destination columns per source column: ceil(2*(Wo-1)/(Wi-1)) + 2 (see ac_range)
+    const int64_t kw = (Wi > 1 && Wo > 1) ? (2 * (Wo - 1) + (Wi - 1) - 1) / (Wi - 1) + 2 : (int64_t)1 << 30;
+    const dim3 grid((unsigned)(B * ly));
+    const int full = FullVec<T>::value;
+    const bool vec = ok && pick_vec<T>(C) > 1;
+#define MRFP_BWD_LAUNCH(VECV, KWV)                                                                                     \
+    hipLaunchKernelGGL((bilinear_bwd_kernel<T, VECV, KWV>), grid, dim3(kThreads), 0, st, (const T*)dy, (T*)dx, (int)B, \
+                       (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly)
+    if (vec) {
+        if (kw <= 4) MRFP_BWD_LAUNCH(full, 4);
+        else if (kw <= 8) MRFP_BWD_LAUNCH(full, 8);
+        else if (kw <= 12) MRFP_BWD_LAUNCH(full, 12);
+        else MRFP_BWD_LAUNCH(full, 0);
+    } else {
+        if (kw <= 4) MRFP_BWD_LAUNCH(1, 4);
+        else if (kw <= 8) MRFP_BWD_LAUNCH(1, 8);
+        else if (kw <= 12) MRFP_BWD_LAUNCH(1, 12);
+        else MRFP_BWD_LAUNCH(1, 0);
+    }
+#undef MRFP_BWD_LAUNCH
+    MRFP_LAUNCH_CHECK();
     return 0;
 }
 template <typename T>

@@ -371,8 +371,36 @@ class _Bilinear(torch.autograd.Function):
         return dx, (dy if ctx.has_add else None), None, None, None
 
 
+class _Broadcast(torch.autograd.Function):
+    """Upsample() of a 1x1 map (the ASPP image-pooling branch, reference deepv3.py:117-121): every output pixel is
+    the source value, so forward is a broadcast store and backward a plane sum (the statistics kernel) instead of
+    one thread gathering a whole plane."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x = _chk(x)
+        B, C = x.shape[0], x.shape[1]
+        S = x.detach().float().reshape(B, C).contiguous()
+        y = empty_cl(B, C, Ho, Wo, x.dtype, x.device)
+        call("mrfp_affine_fwd", None, None, ptr(y), dt(x), B, Ho, Wo, C, Ho, Wo, None, None, None, ptr(S), 1, 0, stream())
+        ctx.dims = (B, C, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        B, C, Ho, Wo = ctx.dims
+        nslab, ws = _stats_fwd(dy, None)
+        dx = empty_cl(B, C, 1, 1, dy.dtype, dy.device)
+        tmp = torch.empty(B * C, dtype=torch.float32, device=dy.device)
+        call("mrfp_mean_finalize", ptr(ws), B, nslab, 1, C, ptr(tmp), ptr(dx), dt(dy), stream())     # count 1: the sum
+        return dx, None, None
+
+
 def upsample_bilinear(x, size, addend=None, channels=None):
     """channels: use only the first `channels` channels of x (x is a channel-padded buffer)."""
+    if x.shape[2] == 1 and x.shape[3] == 1 and addend is None and channels is None:
+        return _Broadcast.apply(x, int(size[0]), int(size[1]))
     return _Bilinear.apply(x, addend, int(size[0]), int(size[1]), channels)
 
 
