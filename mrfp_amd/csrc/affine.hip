@@ -10,7 +10,7 @@
 
 namespace mrfp {
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool RESIZE>
 __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                               T* __restrict__ y, RowGeom g, int ly,
                                                               const float* __restrict__ A, const float* __restrict__ S,
@@ -28,20 +28,23 @@ __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restric
         if (A) load_coef<VEC>(A + cbase + (size_t)cv * VEC, a);
         if (S) load_coef<VEC>(S + cbase + (size_t)cv * VEC, s);
         for (int oh = j; oh < g.Ho; oh += ly) {
-            const int ih = g.tabH ? g.tabH[oh] : oh;
+            const int ih = RESIZE ? g.tabH[oh] : oh;
             const T* xl = x ? x + ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC : nullptr;
             const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
             // 4 independent pixels per trip (up to 8 16-byte loads in flight per lane)
             for (int ow0 = trow; ow0 < g.Wo; ow0 += 4 * L.rowthreads) {
                 VecT<T, VEC> xr[4], rr[4];
+                // unconditional loads from clamped pixel indices, RESIZE as a template parameter: see stats.hip
+                int owc[4], iwv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int ow = ow0 + u * L.rowthreads;
-                    if (ow < g.Wo) {
-                        const int iw = g.tabW ? g.tabW[ow] : ow;
-                        if (xl) xr[u] = load_raw<T, VEC>(xl + (size_t)iw * g.C);
-                        if (res) rr[u] = load_raw<T, VEC>(res + dl + (size_t)ow * g.C);
-                    }
+                    owc[u] = min(ow0 + u * L.rowthreads, g.Wo - 1);
+                    iwv[u] = RESIZE ? g.tabW[owc[u]] : owc[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (xl) xr[u] = load_raw<T, VEC>(xl + (size_t)iwv[u] * g.C);
+                    if (res) rr[u] = load_raw<T, VEC>(res + dl + (size_t)owc[u] * g.C);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -111,13 +114,11 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                 for (int iw0 = trow; iw0 < g.Ws; iw0 += 4 * L.rowthreads) {
                     VecT<T, VEC> dr[4], xr[4], yr[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int iw = iw0 + u * L.rowthreads;
-                        if (iw < g.Ws) {
-                            dr[u] = load_raw<T, VEC>(dy + sl + (size_t)iw * g.C);
-                            if (x && (Q || remask)) xr[u] = load_raw<T, VEC>(x + sl + (size_t)iw * g.C);
-                            if (y) yr[u] = load_raw<T, VEC>(y + sl + (size_t)iw * g.C);
-                        }
+                    for (int u = 0; u < 4; ++u) {      // unconditional, clamped (see stats.hip)
+                        const int iw = min(iw0 + u * L.rowthreads, g.Ws - 1);
+                        dr[u] = load_raw<T, VEC>(dy + sl + (size_t)iw * g.C);
+                        if (x && (Q || remask)) xr[u] = load_raw<T, VEC>(x + sl + (size_t)iw * g.C);
+                        if (y) yr[u] = load_raw<T, VEC>(y + sl + (size_t)iw * g.C);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -211,12 +212,14 @@ static int launch_affine_fwd(const void* x, const void* res, void* y, int64_t B,
     dim3 grid((unsigned)(B * ly));
     const bool vec_ok = pick_vec<T>(C) > 1 && (!x || aligned16(x)) && aligned16(y) && (!res || aligned16(res)) &&
                         (!A || aligned16(A)) && (!S || aligned16(S));
-    if (vec_ok)
-        hipLaunchKernelGGL((affine_fwd_kernel<T, FullVec<T>::value>), grid, dim3(kThreads), 0, st, (const T*)x,
-                           (const T*)res, (T*)y, g, ly, A, S, cpi, relu);
-    else
-        hipLaunchKernelGGL((affine_fwd_kernel<T, 1>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)res, (T*)y, g,
-                           ly, A, S, cpi, relu);
+    const bool resize = tabH != nullptr || tabW != nullptr;
+    if (resize && !(tabH && tabW)) { set_error("affine_fwd: both index tables or none"); return -1; }
+#define MRFP_AFF_LAUNCH(VECV, RS)                                                                                      \
+    hipLaunchKernelGGL((affine_fwd_kernel<T, VECV, RS>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)res,      \
+                       (T*)y, g, ly, A, S, cpi, relu)
+    if (vec_ok) { if (resize) MRFP_AFF_LAUNCH(FullVec<T>::value, true); else MRFP_AFF_LAUNCH(FullVec<T>::value, false); }
+    else { if (resize) MRFP_AFF_LAUNCH(1, true); else MRFP_AFF_LAUNCH(1, false); }
+#undef MRFP_AFF_LAUNCH
     MRFP_LAUNCH_CHECK();
     return 0;
 }

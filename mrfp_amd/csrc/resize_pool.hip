@@ -44,16 +44,14 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(const T* __restr
                 Tap tw[4];
                 VecT<T, VEC> ra[4], rb[4], rc[4], rd[4], re[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ow = ow0 + u * L.rowthreads;
-                    if (ow < Wo) {
-                        tw[u] = ac_tap(sw, ow, Wi);
-                        ra[u] = load_raw<T, VEC>(r0 + (size_t)tw[u].i0 * ldi);
-                        rb[u] = load_raw<T, VEC>(r0 + (size_t)tw[u].i1 * ldi);
-                        rc[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i0 * ldi);
-                        rd[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i1 * ldi);
-                        if (addend) re[u] = load_raw<T, VEC>(addend + dl + (size_t)ow * C);
-                    }
+                for (int u = 0; u < 4; ++u) {          // unconditional loads, clamped column (tail masked at the store)
+                    const int ow = min(ow0 + u * L.rowthreads, Wo - 1);
+                    tw[u] = ac_tap(sw, ow, Wi);
+                    ra[u] = load_raw<T, VEC>(r0 + (size_t)tw[u].i0 * ldi);
+                    rb[u] = load_raw<T, VEC>(r0 + (size_t)tw[u].i1 * ldi);
+                    rc[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i0 * ldi);
+                    rd[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i1 * ldi);
+                    if (addend) re[u] = load_raw<T, VEC>(addend + dl + (size_t)ow * C);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

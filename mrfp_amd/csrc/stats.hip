@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 // MODE 0: s += x, q += x*x                         (forward statistics)
 // MODE 1: s += dy', q += dy'*(x - mean[g,c])       (backward statistics; dy' masked by y > 0)
 // ------------------------------------------------------------------------------------------
-template <typename T, int VEC, int MODE>
+template <typename T, int VEC, int MODE, bool RESIZE>
 __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ fA, const float* __restrict__ fS,
@@ -55,45 +55,61 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
         const bool remask = MODE == 1 && y == nullptr && fA != nullptr;
         if (on) {
             for (int oh = j; oh < g.Ho; oh += ly) {
-                const int ih = g.tabH ? g.tabH[oh] : oh;
+                const int ih = RESIZE ? g.tabH[oh] : oh;
                 const T* xl = x + ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
                 const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
-                // 4 independent pixels per trip: 4 (MODE 0) or up to 12 (MODE 1) 16-byte loads in flight per lane
+                // 4 independent pixels per trip: 4 (MODE 0) or up to 12 (MODE 1) 16-byte loads in flight per lane.
+                // RESIZE is a template parameter: with a run-time `tabW ? tabW[ow] : ow` the compiler parks an
+                // s_waitcnt vmcnt(0) for the table value in front of every pixel's loads and serialises them
+                // (measured: 3.5 TB/s instead of 5 TB/s on the identity geometry).
                 for (int ow0 = trow; ow0 < g.Wo; ow0 += 4 * L.rowthreads) {
+                    // loads are UNCONDITIONAL (pixel index clamped into the line; the tail is masked in the arithmetic
+                    // below): a load inside a divergent `if (ow < Wo)` region is waited for at the region's end
+                    // (s_waitcnt vmcnt(0) per pixel), which leaves 2-3 loads in flight instead of 8-12
                     VecT<T, VEC> xr[4], dr[4], yr[4];
+                    int owc[4], iwv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int ow = ow0 + u * L.rowthreads;
-                        if (ow < g.Wo) {
-                            const int iw = g.tabW ? g.tabW[ow] : ow;
-                            xr[u] = load_raw<T, VEC>(xl + (size_t)iw * g.C);
-                            if (MODE == 1) {
-                                dr[u] = load_raw<T, VEC>(dy + dl + (size_t)ow * g.C);
-                                if (y != nullptr) yr[u] = load_raw<T, VEC>(y + dl + (size_t)ow * g.C);
-                            }
-                        }
+                        owc[u] = min(ow0 + u * L.rowthreads, g.Wo - 1);
+                        iwv[u] = RESIZE ? g.tabW[owc[u]] : owc[u];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int ow = ow0 + u * L.rowthreads;
-                        if (ow < g.Wo) {
-                            float xv[VEC];
-                            cvt_f<T, VEC>(xr[u], xv);
-                            if (MODE == 0) {
+                        xr[u] = load_raw<T, VEC>(xl + (size_t)iwv[u] * g.C);
+                        if (MODE == 1) {
+                            dr[u] = load_raw<T, VEC>(dy + dl + (size_t)owc[u] * g.C);
+                            if (y != nullptr) yr[u] = load_raw<T, VEC>(y + dl + (size_t)owc[u] * g.C);
+                        }
+                    }
+                    // branch-free arithmetic: the line tail and the ReLU mask are selects, not divergent regions
+                    const bool use_y = MODE == 1 && y != nullptr;
 #pragma unroll
-                                for (int i = 0; i < VEC; ++i) { s[i] += xv[i]; q[i] += xv[i] * xv[i]; }
+                    for (int u = 0; u < 4; ++u) {
+                        const bool inside = ow0 + u * L.rowthreads < g.Wo;
+                        float xv[VEC];
+                        cvt_f<T, VEC>(xr[u], xv);
+                        if (MODE == 0) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                const float v = inside ? xv[i] : 0.f;
+                                s[i] += v;
+                                q[i] += v * v;
+                            }
+                        } else {
+                            float dv[VEC], yv[VEC];
+                            cvt_f<T, VEC>(dr[u], dv);
+                            if (use_y) {
+                                cvt_f<T, VEC>(yr[u], yv);
                             } else {
-                                float dv[VEC], yv[VEC];
-                                cvt_f<T, VEC>(dr[u], dv);
-                                if (y != nullptr) cvt_f<T, VEC>(yr[u], yv);
 #pragma unroll
-                                for (int i = 0; i < VEC; ++i) {
-                                    const bool dead = (y != nullptr && !(yv[i] > 0.f)) ||
-                                                      (remask && !(xv[i] * fa[i] + fs[i] > 0.f));
-                                    const float d = dead ? 0.f : dv[i];
-                                    s[i] += d;
-                                    q[i] += d * (xv[i] - mu[i]);
-                                }
+                                for (int i = 0; i < VEC; ++i) yv[i] = 1.f;
+                            }
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                const float gate = use_y ? yv[i] : (remask ? xv[i] * fa[i] + fs[i] : 1.f);
+                                const float d = (inside && gate > 0.f) ? dv[i] : 0.f;
+                                s[i] += d;
+                                q[i] += d * (xv[i] - mu[i]);
                             }
                         }
                     }
@@ -130,12 +146,14 @@ static int launch_stats(const void* x, const void* dy, const void* y, const floa
     const int ly = lines_per_image(B, Ho);
     dim3 grid((unsigned)(B * ly));
     const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(x) && (MODE == 0 || (aligned16(dy) && (y == nullptr || aligned16(y))));
-    if (vec_ok)
-        hipLaunchKernelGGL((stats_kernel<T, FullVec<T>::value, MODE>), grid, dim3(kThreads), 0, st, (const T*)x,
-                           (const T*)dy, (const T*)y, mean, fA, fS, per_image, g, ly, ws);
-    else
-        hipLaunchKernelGGL((stats_kernel<T, 1, MODE>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)dy,
-                           (const T*)y, mean, fA, fS, per_image, g, ly, ws);
+    const bool resize = tabH != nullptr || tabW != nullptr;
+    if (resize && !(tabH && tabW)) { set_error("stats: both index tables or none"); return -1; }
+#define MRFP_STATS_LAUNCH(VECV, RS)                                                                                    \
+    hipLaunchKernelGGL((stats_kernel<T, VECV, MODE, RS>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)dy,      \
+                       (const T*)y, mean, fA, fS, per_image, g, ly, ws)
+    if (vec_ok) { if (resize) MRFP_STATS_LAUNCH(FullVec<T>::value, true); else MRFP_STATS_LAUNCH(FullVec<T>::value, false); }
+    else { if (resize) MRFP_STATS_LAUNCH(1, true); else MRFP_STATS_LAUNCH(1, false); }
+#undef MRFP_STATS_LAUNCH
     MRFP_LAUNCH_CHECK();
     return 0;
 }
