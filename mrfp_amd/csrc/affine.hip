@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restric
 // Backward, walking SOURCE lines.  invH[2*ih], invH[2*ih+1] = half-open range of destination rows that
 // read source row ih (NULL = identity).  dres (destination geometry) is only supported with
 // identity maps (the residual branches of the network never sit behind a resize).
-template <typename T, int VEC>
+template <typename T, int VEC, int KR>
 __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                               const T* __restrict__ y, T* __restrict__ dx,
                                                               T* __restrict__ dres, RowGeom g, int ly,
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
             load_coef<VEC>(fA + cbase + (size_t)cv * VEC, fa);
             load_coef<VEC>(fS + cbase + (size_t)cv * VEC, fs);
         }
-        if (!invH && !invW) {
-            // identity geometry (every BN / IN / NP+ outside the HRFP branch): 4 pixels per trip, loads first
+        if (KR < 0) {
+            // identity geometry (own instantiation, KR = -1: keeps its register count independent of the resize paths) (every BN / IN / NP+ outside the HRFP branch): 4 pixels per trip, loads first
             for (int ih = j; ih < g.Hs; ih += ly) {
                 const size_t sl = ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
                 for (int iw0 = trow; iw0 < g.Ws; iw0 += 4 * L.rowthreads) {
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
             }
             continue;
         }
+        if (KR >= 0)
         for (int ih = j; ih < g.Hs; ih += ly) {
             const int oh0 = invH ? invH[2 * ih] : ih, oh1 = invH ? invH[2 * ih + 1] : ih + 1;
             const size_t sl = ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
@@ -155,6 +156,47 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                 float acc[VEC], xv[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { acc[i] = 0.f; xv[i] = 0.f; }
+                const float n = (float)((oh1 - oh0) * (ow1 - ow0));
+                if (KR > 0 && oh1 - oh0 <= KR && ow1 - ow0 <= KR) {
+                    // bounded fan-in (nearest resize by a small factor; launched only without y / dres): the KR*KR
+                    // candidate gradients are loaded unconditionally from clamped positions, all in flight together;
+                    // absent ones are masked out
+                    VecT<T, VEC> xr, dr[KR > 0 ? KR * KR : 1];
+                    const bool need_x = x && (Q || remask);
+                    if (need_x) xr = load_raw<T, VEC>(x + sl + (size_t)iw * g.C);
+#pragma unroll
+                    for (int kh = 0; kh < KR; ++kh) {
+                        const int oh = min(oh0 + kh, g.Ho - 1);
+                        const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
+#pragma unroll
+                        for (int kw = 0; kw < KR; ++kw)
+                            dr[kh * KR + kw] = load_raw<T, VEC>(dy + dl + (size_t)min(ow0 + kw, g.Wo - 1) * g.C);
+                    }
+                    if (need_x) cvt_f<T, VEC>(xr, xv);
+                    float keep[VEC];      // the ReLU mask depends on the source pixel only
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) keep[i] = (!remask || xv[i] * fa[i] + fs[i] > 0.f) ? 1.f : 0.f;
+#pragma unroll
+                    for (int kh = 0; kh < KR; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < KR; ++kw) {
+                            const bool have = oh0 + kh < oh1 && ow0 + kw < ow1;
+                            float dv[VEC];
+                            cvt_f<T, VEC>(dr[kh * KR + kw], dv);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) acc[i] += (have && keep[i] != 0.f) ? dv[i] : 0.f;
+                        }
+                    float o[VEC];
+                    if (x && Q) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * (q[i] * xv[i] + r[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * r[i];
+                    }
+                    store_f<T, VEC>(dx + sl + (size_t)iw * g.C, o);
+                    continue;
+                }
                 if (x && (Q || remask)) load_f<T, VEC>(x + sl + (size_t)iw * g.C, xv);
                 for (int oh = oh0; oh < oh1; ++oh) {
                     const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
@@ -175,7 +217,6 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                         for (int i = 0; i < VEC; ++i) acc[i] += dv[i];
                     }
                 }
-                const float n = (float)((oh1 - oh0) * (ow1 - ow0));
                 float o[VEC];
                 if (x && Q) {
 #pragma unroll
@@ -235,12 +276,30 @@ static int launch_affine_bwd(const void* dy, const void* x, const void* y, void*
     const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(dy) && aligned16(dx) && (!x || aligned16(x)) &&
                         (!y || aligned16(y)) && (!dres || aligned16(dres)) && (!P || aligned16(P)) &&
                         (!Q || aligned16(Q)) && (!R || aligned16(R)) && (!fA || (aligned16(fA) && aligned16(fS)));
-    if (vec_ok)
-        hipLaunchKernelGGL((affine_bwd_kernel<T, FullVec<T>::value>), grid, dim3(kThreads), 0, st, (const T*)dy,
-                           (const T*)x, (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, fA, fS, cpi);
-    else
-        hipLaunchKernelGGL((affine_bwd_kernel<T, 1>), grid, dim3(kThreads), 0, st, (const T*)dy, (const T*)x,
-                           (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, fA, fS, cpi);
+    // fan-in bound of a nearest resize: at most ceil(out/in) destinations per source and axis (+1 for the float
+    // rounding of ATen's index rule); the kernel checks the exact count per pixel and falls back to plain loops
+    int kr = 0;
+    if (invH && invW && !y && !dres) {
+        const int64_t kh = (Ho + Hs - 1) / Hs + 1, kw = (Wo + Ws - 1) / Ws + 1;
+        const int64_t k = kh > kw ? kh : kw;
+        kr = k <= 2 ? 2 : k <= 3 ? 3 : 0;
+    }
+#define MRFP_AFFB_LAUNCH(VECV, KRV)                                                                                    \
+    hipLaunchKernelGGL((affine_bwd_kernel<T, VECV, KRV>), grid, dim3(kThreads), 0, st, (const T*)dy, (const T*)x,      \
+                       (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, fA, fS, cpi)
+    const bool identity = !invH && !invW;
+    if (vec_ok) {
+        if (identity) MRFP_AFFB_LAUNCH(FullVec<T>::value, -1);
+        else if (kr == 2) MRFP_AFFB_LAUNCH(FullVec<T>::value, 2);
+        else if (kr == 3) MRFP_AFFB_LAUNCH(FullVec<T>::value, 3);
+        else MRFP_AFFB_LAUNCH(FullVec<T>::value, 0);
+    } else {
+        if (identity) MRFP_AFFB_LAUNCH(1, -1);
+        else if (kr == 2) MRFP_AFFB_LAUNCH(1, 2);
+        else if (kr == 3) MRFP_AFFB_LAUNCH(1, 3);
+        else MRFP_AFFB_LAUNCH(1, 0);
+    }
+#undef MRFP_AFFB_LAUNCH
     MRFP_LAUNCH_CHECK();
     return 0;
 }

@@ -59,6 +59,30 @@ def main():
                   flush=True)
         del xs, dys
         torch.cuda.empty_cache()
+    # HRFP stages: conv output [Hs,Ws] -> nearest resize -> BN -> ReLU at [Ho,Wo] (the resize is an index table inside
+    # the kernels; algorithmic bytes: source tensor for reads, destination tensor for dy / y)
+    for (B, C, Hs, Ho) in [(16, 128, 277, 332), (16, 256, 384, 321), (16, 64, 192, 231)]:
+        plan = ops.nearest_plan(Hs, Hs, size=(Ho, Ho), device=DEV)
+        sb, db = B * C * Hs * Hs * 2, B * C * Ho * Ho * 2
+        n = max(2, int(700e6 // (sb + 2 * db)) + 1)
+        xs = [ops.empty_cl(B, C, Hs, Hs, dtype, DEV).normal_() for _ in range(n)]
+        dys = [ops.empty_cl(B, C, Ho, Ho, dtype, DEV).normal_() for _ in range(n)]
+        coef = torch.rand(8 * C, device=DEV) + 0.5
+        A, S, P, Q, R, mean = (coef[i * C:(i + 1) * C] for i in range(6))
+        tests = {
+            "resize stats_fwd (read x)": (sb, lambda i: ops._stats_fwd(xs[i], plan)),
+            "resize affine_fwd relu (read x, write y)": (sb + db, lambda i: ops._affine_fwd(xs[i], None, A, S, False, True, plan)),
+            "resize stats_bwd remask (read dy, x)": (sb + db, lambda i: ops._stats_bwd(dys[i], xs[i], None, mean, False, plan, A, S)),
+            "resize affine_bwd remask (read dy, x, write dx)": (2 * sb + db, lambda i: ops._affine_bwd(dys[i], xs[i], None, P, Q, R, False,
+                                                                                                      plan, False, xs[i], A, S)),
+        }
+        for name, (alg, fn) in tests.items():
+            ms = timed(fn, n, reps)
+            print(json.dumps({"shape": [B, C, Hs, Hs], "to": Ho, "kernel": name, "MB": round(alg / 1e6, 1), "ms": round(ms, 4),
+                              "GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / HBM_PEAK, 3)}),
+                  flush=True)
+        del xs, dys
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
