@@ -75,6 +75,12 @@ class _ConvBnRelu(nn.Sequential):
     def forward(self, x):
         return self[1].fused(self[0](x), relu=True)
 
+    def forward_skip(self, x):
+        """(module(x), alias of x): gradients arriving on the alias are added by this conv's dgrad epilogue, so a
+        tensor with several consumers is chained through them instead of being summed by separate passes."""
+        y, xs = self[0].forward_skip(x)
+        return self[1].fused(y, relu=True), xs
+
 
 class _AtrousSpatialPyramidPoolingModule(nn.Module):
     """reference deepv3.py:64-126: image pooling + 1x1 + three dilated 3x3 branches, concatenated
@@ -100,9 +106,12 @@ class _AtrousSpatialPyramidPoolingModule(nn.Module):
         self.img_conv = _ConvBnRelu(in_dim, 256, 1)
 
     def forward(self, x):
-        img = self.img_conv(ops.global_avg_pool(x))
-        outs = [Upsample(img, x.shape[2:])] + [f(x) for f in self.features]
-        return ops.concat_channels(outs)
+        outs, cur = [], x
+        for f in self.features:          # x is chained through its five consumers (see _ConvBnRelu.forward_skip)
+            y, cur = f.forward_skip(cur)
+            outs.append(y)
+        img = self.img_conv(ops.global_avg_pool(cur))
+        return ops.concat_channels([Upsample(img, x.shape[2:])] + outs)
 
 
 class _DeepLabBase(nn.Module):
@@ -241,14 +250,17 @@ class MRFPPlus(_DeepLabBase):
         resize = [dict(scale=1.205), dict(scale=1.2), dict(scale=1.2), dict(size=(int(h / 2), int(w / 2))),
                   dict(size=(int(h / 2), int(w / 2))), dict(scale=0.838), dict(scale=0.798),
                   dict(size=(math.ceil(h / 4), math.ceil(w / 4)))]
-        t, dec = xp, None
+        t, dec, xp_alias = xp, None, xp
         for i, ((conv, bn), rs) in enumerate(zip(self.hrfp_layers(), resize)):
-            t = conv(t)
+            if i == 0:            # xp also feeds the trunk: the trunk-side gradient rides in this conv's dgrad epilogue
+                t, xp_alias = conv.forward_skip(t)
+            elif i == 4:          # OCout_dec also feeds the O2 add: same chaining
+                t, dec = conv.forward_skip(t)
+            else:
+                t = conv(t)
             plan = ops.nearest_plan(t.shape[2], t.shape[3], device=t.device, **rs)
             t = bn.fused(t, relu=True, plan=plan)
-            if i == 3:
-                dec = t
-        return dec, t
+        return dec, t, xp_alias
 
     def forward(self, x, gts=None, training=True):
         p, p2, p3 = self.rng.toggles()
@@ -260,20 +272,20 @@ class MRFPPlus(_DeepLabBase):
         xp, w_arr = self._stem(x)
         if training == True and self.fourier_perturb is not None:      # noqa: E712  (extension, default off)
             xp = self.fourier_perturb(xp)
+        OCout_dec, OCout, xp = self._hrfp(xp, h, w)   # always computed, as the reference does (no RNG inside)
         t = xp
         if npp:
             t = self.Normalization_Perturbation_Plus(xp, "np1")
-        OCout_dec, OCout = self._hrfp(xp, h, w)       # always computed, as the reference does
         if o1:
             t = ops.add(OCout, t)
         x_tuple = self.layer1([t, w_arr])
         if npp:
             x_tuple[0] = self.Normalization_Perturbation_Plus(x_tuple[0], "np2")
+        dec0_fine, x_tuple[0] = self.bot_fine.forward_skip(x_tuple[0])      # low-level features: decoder + layer2
         low_level = x_tuple[0]
         x_tuple = self.layer4(self.layer3(self.layer2(x_tuple)))
         t = self.aspp(x_tuple[0])
         dec0_up = self.bot_aspp(t)
-        dec0_fine = self.bot_fine(low_level)
         dec0_up = Upsample(dec0_up, low_level.shape[2:])
         dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))
         if o2:                                         # "+" of MRFP+: deepv3.py:355-357, one fused pass

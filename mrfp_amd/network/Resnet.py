@@ -67,10 +67,10 @@ class _Block(nn.Module):
 
     def _first_conv(self, x):
         """conv1(x) and the tensor the skip connection should read: an alias of x whose gradient the conv1 dgrad
-        kernel accumulates (identity blocks), or x itself (blocks with a downsample branch)."""
-        if self.downsample is None:
-            return self.conv1.forward_skip(x)
-        return self.conv1(x), x
+        kernel accumulates."""
+        # (blocks with a downsample branch feed the alias to the downsample conv: its dgrad output becomes the addend of
+        #  conv1's dgrad launch instead of a separate accumulation pass over the block input)
+        return self.conv1.forward_skip(x)
 
     def _tail(self, last_bn, out, x, w_arr):
         residual = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))
