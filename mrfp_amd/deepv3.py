@@ -116,6 +116,8 @@ class _AtrousSpatialPyramidPoolingModule(nn.Module):
 
 class _DeepLabBase(nn.Module):
     def _build_trunk_and_head(self, num_classes, trunk, wt_layer):
+        if trunk == "wider_resnet38_a2" and self._allow_101:
+            return self._build_wrn_trunk_and_head(num_classes)
         if trunk == "resnet-50":
             resnet = Resnet.resnet50(wt_layer=wt_layer)
         elif trunk == "resnet-101" and self._allow_101:
@@ -139,7 +141,24 @@ class _DeepLabBase(nn.Module):
         else:
             print("Not using Dilation ")
         self.output_stride = 16
-        self.aspp = _AtrousSpatialPyramidPoolingModule(2048, 256, output_stride=16)
+        self._build_head(num_classes, 2048)
+
+    def _build_wrn_trunk_and_head(self, num_classes):
+        """BUILD-DEFINED composition (BASELINE.json configs[4]; the reference's MRFPPlus only takes resnet-50 and its
+        WiderResNet is not wired into any of its DeepLab variants): WiderResNet-38-A2, dilated (output stride 8).
+        The trunk is cut where the ResNet trunks are cut: `stem` = mod1 -> pool2 -> mod2 -> pool3 (128 ch, 1/4
+        resolution) is what HRFP and the first NP+ see, `mod3` (256 ch, 1/4) plays layer1 (second NP+, low-level
+        skip), mod4..mod7 + bn_out (4096 ch, 1/8) feed an output-stride-8 ASPP."""
+        from .network import wider_resnet
+        wrn = wider_resnet.wider_resnet38_a2(classes=0, dilation=True)
+        self._trunk = [wrn]
+        for name in ("mod1", "pool2", "mod2", "pool3", "mod3", "mod4", "mod5", "mod6", "mod7", "bn_out"):
+            setattr(self, name, getattr(wrn, name))
+        self.output_stride = 8
+        self._build_head(num_classes, 4096)
+
+    def _build_head(self, num_classes, trunk_channels):
+        self.aspp = _AtrousSpatialPyramidPoolingModule(trunk_channels, 256, output_stride=self.output_stride)
         self.bot_fine = _ConvBnRelu(256, 48, 1)
         self.bot_aspp = _ConvBnRelu(1280, 256, 1)
         self.final1 = nn.Sequential(HipConv2d(304, 256, kernel_size=3, padding=1, bias=False), Norm2d(256),
@@ -162,11 +181,26 @@ class _DeepLabBase(nn.Module):
         """layer0: conv(s) -> norm -> ReLU -> maxpool (reference deepv3.py:309-315)."""
         trunk = self._trunk[0]
         w_arr = []
+        if not isinstance(trunk, (Resnet.ResNet, Resnet.ResNet3X3)):
+            return trunk.stem(x), w_arr                # WiderResNet: mod1 -> pool2 -> mod2 -> pool3
         if isinstance(trunk, Resnet.ResNet3X3):
             t = trunk.stem(x, w_arr)
         else:
             t = Resnet._norm_relu(self.layer0[1], trunk.wt_layer[2], self.layer0[0](ops.as_activation(x)), w_arr)
         return ops.max_pool_3x3_s2(t), w_arr
+
+    def _low(self, t, w_arr):
+        """stem output -> low-level features (256 ch, 1/4): layer1 (reference deepv3.py:331-333) / mod3."""
+        if hasattr(self, "layer1"):
+            return self.layer1([t, w_arr])[0]
+        return self.mod3(t)
+
+    def _high(self, t, w_arr):
+        """low-level features -> ASPP input: layer2..layer4 (reference deepv3.py:338-344) / mod4..mod7 + bn_out."""
+        if hasattr(self, "layer1"):
+            return self.layer4(self.layer3(self.layer2([t, w_arr])))[0]
+        t = self.mod7(self.mod6(self.mod5(self.mod4(t))))
+        return self.bn_out[0].fused(t, relu=True)
 
     def _final1(self, d):
         d = self.final1[1].fused(self.final1[0](d), relu=True)
@@ -215,7 +249,7 @@ class MRFPPlus(_DeepLabBase):
         self._build_trunk_and_head(num_classes, trunk, wt_layer)
 
         # HRFP: frozen random over-complete auto-encoder (reference deepv3.py:221-237)
-        stem_c = 128 if trunk == "resnet-101" else 64
+        stem_c = 64 if trunk == "resnet-50" else 128
         enc = [(stem_c, 64, 1), (64, 64, 1), (64, 128, 2), (128, 256, 2)]
         dec = [(256, 128, 1), (128, 64, 1), (64, 64, 2), (64, stem_c, 2)]
         for i, (ci, co, d) in enumerate(enc, 1):
@@ -278,13 +312,11 @@ class MRFPPlus(_DeepLabBase):
             t = self.Normalization_Perturbation_Plus(xp, "np1")
         if o1:
             t = ops.add(OCout, t)
-        x_tuple = self.layer1([t, w_arr])
+        t = self._low(t, w_arr)
         if npp:
-            x_tuple[0] = self.Normalization_Perturbation_Plus(x_tuple[0], "np2")
-        dec0_fine, x_tuple[0] = self.bot_fine.forward_skip(x_tuple[0])      # low-level features: decoder + layer2
-        low_level = x_tuple[0]
-        x_tuple = self.layer4(self.layer3(self.layer2(x_tuple)))
-        t = self.aspp(x_tuple[0])
+            t = self.Normalization_Perturbation_Plus(t, "np2")
+        dec0_fine, low_level = self.bot_fine.forward_skip(t)      # low-level features: decoder + layer2
+        t = self.aspp(self._high(low_level, w_arr))
         dec0_up = self.bot_aspp(t)
         dec0_up = Upsample(dec0_up, low_level.shape[2:])
         dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))

@@ -467,6 +467,34 @@ def global_avg_pool(x):
 
 
 # ------------------------------------------------------------------------------------------
+# per-(image, channel) scale: Dropout2d
+# ------------------------------------------------------------------------------------------
+class _ChannelScale(torch.autograd.Function):
+    """y[b,c,:,:] = x[b,c,:,:] * m[b,c] (nn.Dropout2d with its keep-mask / (1-p) given explicitly; reference
+    network/wider_resnet.py:302, 333-338): one apply pass forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        x = _chk(x)
+        B, C = x.shape[0], x.shape[1]
+        m = m.detach().to(device=x.device, dtype=torch.float32).reshape(B * C).contiguous()
+        y = _affine_fwd(x, None, m, None, True, False, None)
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        dx, _ = _affine_bwd(dy, None, None, m, None, None, True, None, False, dy)
+        return dx, None
+
+
+def channel_scale(x, m):
+    return _ChannelScale.apply(x, m)
+
+
+# ------------------------------------------------------------------------------------------
 # elementwise add
 # ------------------------------------------------------------------------------------------
 class _Add(torch.autograd.Function):

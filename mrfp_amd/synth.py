@@ -66,13 +66,13 @@ def synth_batch(batch: int, height: int, width: int, seed: int = 1, num_classes:
     return x, y
 
 
-def synth_noise(batch: int, seed: int = 2):
+def synth_noise(batch: int, seed: int = 2, channels=(64, 256)):
     """The two NP+ normal-draw pairs of one forward: alpha ~ N(1, .75), beta_noise ~ N(0, .75)
-    (reference deepv3.py:274-275) for the 64- and the 256-channel call sites."""
+    (reference deepv3.py:274-275) for the 64- and the 256-channel call sites (128 / 256 with a deep-stem trunk)."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     out = {}
-    for name, c in (("np1", 64), ("np2", 256)):
+    for name, c in (("np1", channels[0]), ("np2", channels[1])):
         out[name + "_alpha"] = 1.0 + 0.75 * torch.randn(batch, c, 1, 1, generator=g)
         out[name + "_beta"] = 0.75 * torch.randn(batch, c, 1, 1, generator=g)
     return out

@@ -189,16 +189,77 @@ def hrfp_branch(sd, xp: Tensor, h: int, w: int, train: bool, new_stats=None,
     return dec_tap, t
 
 
-def aspp(sd, x: Tensor, train: bool, new_stats=None) -> Tensor:
-    """reference deepv3.py:114-126; output channel order: img-pool, 1x1, d6, d12, d18."""
+def aspp(sd, x: Tensor, train: bool, new_stats=None, rates=(6, 12, 18)) -> Tensor:
+    """reference deepv3.py:114-126; output channel order: img-pool, 1x1, d6, d12, d18 (rates doubled at output
+    stride 8, deepv3.py:82-85)."""
     size = x.shape[2:]
     img = F.adaptive_avg_pool2d(x, 1)
     img = F.relu(batch_norm(sd, "aspp.img_conv.1", conv(sd, "aspp.img_conv.0", img), train, new_stats))
     outs = [upsample_bilinear_ac(img, size)]
-    for i, r in enumerate((0, 6, 12, 18)):
+    for i, r in enumerate((0,) + tuple(rates)):
         y = conv(sd, f"aspp.features.{i}.0", x, padding=r, dilation=max(r, 1))
         outs.append(F.relu(batch_norm(sd, f"aspp.features.{i}.1", y, train, new_stats)))
     return torch.cat(outs, 1)
+
+
+# --------------------------------------------------------------------------------------
+# WiderResNet-A2 (reference network/wider_resnet.py:64-181, 267-376)
+# --------------------------------------------------------------------------------------
+def _wrn_block(sd, pre, x, stride, dilation, train, new_stats, drop_mask):
+    """IdentityResidualBlock.forward (reference wider_resnet.py:169-181): pre-activation bn1; shortcut = proj_conv(bn1)
+    when the block changes shape, else x; two 3x3 convs or a 1x1-3x3-1x1 bottleneck; Dropout2d (given as an explicit
+    keep-mask / (1-p) of shape [B,C,1,1]) in front of the last conv."""
+    bottleneck = pre + "convs.conv3.weight" in sd
+    b1 = F.relu(batch_norm(sd, pre + "bn1.0", x, train, new_stats))
+    shortcut = conv(sd, pre + "proj_conv", b1, stride=stride) if pre + "proj_conv.weight" in sd else x
+    if not bottleneck:
+        out = conv(sd, pre + "convs.conv1", b1, stride=stride, padding=dilation, dilation=dilation)
+        out = F.relu(batch_norm(sd, pre + "convs.bn2.0", out, train, new_stats))
+        if drop_mask is not None:
+            out = out * drop_mask
+        out = conv(sd, pre + "convs.conv2", out, padding=dilation, dilation=dilation)
+    else:
+        out = conv(sd, pre + "convs.conv1", b1, stride=stride)
+        out = F.relu(batch_norm(sd, pre + "convs.bn2.0", out, train, new_stats))
+        out = conv(sd, pre + "convs.conv2", out, padding=dilation, dilation=dilation)
+        out = F.relu(batch_norm(sd, pre + "convs.bn3.0", out, train, new_stats))
+        if drop_mask is not None:
+            out = out * drop_mask
+        out = conv(sd, pre + "convs.conv3", out)
+    return out + shortcut
+
+
+def _wrn_module(sd, name, x, train, new_stats, drop_masks, dilated=True):
+    """One `modK` Sequential; strides / dilations as WiderResNetA2.__init__ assigns them (wider_resnet.py:319-331):
+    dilated: mod4.block1 stride 2, mod5 dilation 2, mod6/mod7 dilation 4; Dropout2d in mod6 / mod7."""
+    mod_id = int(name[3:]) - 2
+    n = sum(1 for k in sd if k.startswith(name + ".block") and k.endswith(".bn1.0.weight"))
+    for b in range(1, n + 1):
+        if dilated:
+            dil = 2 if mod_id == 3 else 4 if mod_id > 3 else 1
+            stride = 2 if b == 1 and mod_id == 2 else 1
+        else:
+            dil = 1
+            stride = 2 if b == 1 and 2 <= mod_id <= 4 else 1
+        key = "%s.block%d" % (name, b)
+        mask = drop_masks.get(key) if (train and drop_masks is not None) else None
+        x = _wrn_block(sd, key + ".", x, stride, dil, train, new_stats, mask)
+    return x
+
+
+def wider_resnet_a2(sd, img: Tensor, train: bool, new_stats=None, drop_masks=None, taps: Optional[dict] = None,
+                    dilated: bool = True) -> Tensor:
+    """WiderResNetA2.forward without classifier (reference wider_resnet.py:366-376)."""
+    t = conv(sd, "mod1.conv1", img, padding=1)
+    t = _wrn_module(sd, "mod2", F.max_pool2d(t, 3, 2, 1), train, new_stats, drop_masks, dilated)
+    t = _wrn_module(sd, "mod3", F.max_pool2d(t, 3, 2, 1), train, new_stats, drop_masks, dilated)
+    if taps is not None:
+        taps["mod3"] = t
+    for m in ("mod4", "mod5", "mod6", "mod7"):
+        t = _wrn_module(sd, m, t, train, new_stats, drop_masks, dilated)
+        if taps is not None:
+            taps[m] = t
+    return F.relu(batch_norm(sd, "bn_out.0", t, train, new_stats))
 
 
 def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None, *,
@@ -227,7 +288,13 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
             return batch_norm(sd, key, v, bn_train, new_stats)
         return instance_norm(sd, key, v)
 
-    if "layer0.3.weight" in sd:
+    wrn = "mod1.conv1.weight" in sd
+    if wrn:
+        # BUILD-DEFINED composition for trunk='wider_resnet38_a2' (BASELINE.json configs[4]; PARITY UNPINNED as a whole,
+        # the trunk arithmetic itself is pinned by tests/golden/wrn38.npz): stem = mod1 -> pool2 -> mod2 -> pool3
+        t = conv(sd, "mod1.conv1", x, padding=1)
+        t = _wrn_module(sd, "mod2", F.max_pool2d(t, 3, 2, 1), bn_train, new_stats, noise)
+    elif "layer0.3.weight" in sd:
         # deep stem of ResNet3X3 (reference Resnet.py:350-435, 475-496): three 3x3 convs; layer0 =
         # Sequential(conv1,bn1,relu1,conv2,bn2,relu2,conv3,bn3,relu3,maxpool) -- a build-defined composition
         # for trunk='resnet-101' (the reference's MRFPPlus only accepts resnet-50)
@@ -247,6 +314,18 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
         oc_dec, oc = hrfp_branch(sd, xp, h, w, bn_train, new_stats, taps)
         if o1:
             t = oc + t
+    if wrn:
+        t = _wrn_module(sd, "mod3", t, bn_train, new_stats, noise)
+        if npp:
+            t = np_plus(t, noise["np2_alpha"], noise["np2_beta"])
+        low = t
+        taps["layer1"] = low
+        for m in ("mod4", "mod5", "mod6", "mod7"):
+            t = _wrn_module(sd, m, t, bn_train, new_stats, noise)
+        t = F.relu(batch_norm(sd, "bn_out.0", t, bn_train, new_stats))
+        taps["layer4"] = t
+        return _decoder(sd, t, low, oc_dec if perturb else None, o2, h, w, gts, training, bn_train, new_stats, taps,
+                        rates=(12, 24, 36))
     nblk = {n: sum(1 for k in sd if k.startswith(n + ".") and k.endswith(".conv1.weight")) for n in
             ("layer1", "layer2", "layer3", "layer4")}
     iw_l1 = 4 if "layer1.%d.instance_norm_layer.weight" % (nblk["layer1"] - 1) in sd else 0
@@ -264,7 +343,12 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
     t = _stage(sd, "layer4", 512, nblk["layer4"], 1, 2, t, 0, bn_train, new_stats)
     taps["layer4"] = t
 
-    t = aspp(sd, t, bn_train, new_stats)
+    return _decoder(sd, t, low, oc_dec if perturb else None, o2, h, w, gts, training, bn_train, new_stats, taps)
+
+
+def _decoder(sd, t, low, oc_dec, o2, h, w, gts, training, bn_train, new_stats, taps, rates=(6, 12, 18)):
+    """ASPP + DeepLabV3+ decoder + the "+" of MRFP+ + loss (reference deepv3.py:345-367)."""
+    t = aspp(sd, t, bn_train, new_stats, rates)
     taps["aspp"] = t
     up = F.relu(batch_norm(sd, "bot_aspp.1", conv(sd, "bot_aspp.0", t), bn_train, new_stats))
     fine = F.relu(batch_norm(sd, "bot_fine.1", conv(sd, "bot_fine.0", low), bn_train, new_stats))

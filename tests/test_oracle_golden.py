@@ -115,3 +115,30 @@ def test_hrfp_size_chain_and_nearest_index(hw):
                else F.interpolate(probe, size=(1, out))).flatten().long().numpy()
         np.testing.assert_array_equal(got, orc.nearest_src_index(size, out, sf))
         size = out
+
+
+def test_wider_resnet38_trunk_matches_reference():
+    """oracle.wider_resnet_a2 against tests/golden/wrn38.npz (produced by the reference's network/wider_resnet.py,
+    tests/golden/make_golden_wrn.py): train mode with the injected Dropout2d masks, backward, eval mode."""
+    from wrn_common import GW, stats, trunk_case
+    sd, x, gy, masks = trunk_case()
+    assert len(sd) == 228 and sum(v.numel() for v in sd.values() if v.is_floating_point()) == 105118656
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    work = {k: v.clone() for k, v in sd.items()}
+    work.update(leaf)
+    new_stats, taps = {}, {}
+    out = orc.wider_resnet_a2(work, x, True, new_stats=new_stats, drop_masks=masks, taps=taps)
+    np.testing.assert_allclose(stats(out), GW["out_stats"], rtol=1e-5)
+    np.testing.assert_allclose(out[:, 100:108, 2:6, 2:6].detach().numpy(), GW["out_crop"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(stats(taps["mod3"]), GW["mod3_stats"], rtol=1e-5)
+    (out * gy).sum().backward()
+    for f in GW.files:
+        if f.startswith("grad_l2/"):
+            k = f[len("grad_l2/"):]
+            ref = float(GW[f])
+            assert abs(leaf[k].grad.double().pow(2).sum().sqrt().item() - ref) / ref < 1e-4, k
+        if f.startswith("running/"):
+            np.testing.assert_allclose(new_stats[f[len("running/"):]][:8].numpy(), GW[f], rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        oe = orc.wider_resnet_a2({k: v.clone() for k, v in sd.items()}, x, False)
+    np.testing.assert_allclose(stats(oe), GW["eval_out_stats"], rtol=1e-5)
