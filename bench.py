@@ -32,8 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--trunk", default="resnet-101", choices=["resnet-50", "resnet-101"])
+    ap.add_argument("--trunk", default="resnet-101", choices=["resnet-50", "resnet-101", "wider_resnet38_a2"])
     ap.add_argument("--size", type=int, default=768)
+    ap.add_argument("--width", type=int, default=0, help="input width when not square (configs[4]: --size 1024 --width 2048)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--backend", default="hip", choices=["hip", "miopen"])
@@ -144,7 +145,8 @@ def main():
     model = model.to(dev).train()
     model.rng = deepv3.InjectedRandom((True, True, True), None, reinit=True)   # all perturbations on, HRFP re-drawn
     trainer = Trainer(model)
-    x, y = synth.synth_batch(args.batch, args.size, args.size, seed=1 + rank)
+    width = args.width or args.size
+    x, y = synth.synth_batch(args.batch, args.size, width, seed=1 + rank)
     x, y = x.to(dev), y.to(dev)
 
     for _ in range(args.warmup):
@@ -181,7 +183,7 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "%s DeepLabV3+ + MRFP+ (HRFP+NP+ on, HRFP re-drawn every step), %dx%d, "
                                       "%d images/GPU, fwd+bwd+SGD, synthetic 19-class, random-init weights"
-                                      % (args.trunk, args.size, args.size, args.batch),
+                                      % (args.trunk, args.size, width, args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "conv_backend": args.backend, "final_loss": round(lossv, 5)},
                "roofline": roof}
