@@ -924,7 +924,14 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& s
     const int wn = 4 / wm;
     const int64_t tiles = ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
     const int64_t nkt = (M + bkp - 1) / bkp;
-    int64_t sp = 768 / tiles;     // ~3 workgroups per CU; every extra split costs an fp32 slab of the whole dW
+    static int target = 0;        // workgroups to aim for (MRFP_WGRAD_WGS for A/B runs).  Measured in the bench workload:
+                                  // 384 / 512 / 768 / 1024 -> 46.9 / 46.3 / 46.9 / 48.2 ms of convolutions per step
+    if (target == 0) {
+        const char* e = getenv("MRFP_WGRAD_WGS");
+        target = e ? atoi(e) : 512;
+        if (target < 64) target = 512;
+    }
+    int64_t sp = target / tiles;  // every extra split costs an fp32 slab of the whole dW
     if (sp < 1) sp = 1;
     if (sp > nkt) sp = nkt;
     int64_t per = (nkt + sp - 1) / sp;        // K' tiles per split
