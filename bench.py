@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--width", type=int, default=0, help="input width when not square (configs[4]: --size 1024 --width 2048)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--backend", default="hip", choices=["hip", "miopen"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -135,7 +135,7 @@ def main():
     from mrfp_amd.config import cfg
     from mrfp_amd.harness import Trainer
     cfg.MODEL.CONV_BACKEND = args.backend
-    cfg.MODEL.ACT_DTYPE = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg.MODEL.ACT_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
 
     import contextlib
     import io
@@ -237,7 +237,7 @@ def conv_roofline(model, trainer, x, y, args):
         with open(args.dump_convs, "w") as f:
             json.dump([{"name": n, "args": sh, "ms": m, "tflops": fl / (m * 1e-3) / 1e12 if m > 0 else 0, "gflop": fl / 1e9}
                        for (n, sh), m, fl in zip(shapes, ms, flops)], f)
-    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # f16 and bf16 MFMA: same dense rate
     ach = tot_f / (tot_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(ms),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

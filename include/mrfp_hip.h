@@ -9,7 +9,7 @@
  *
  * Conventions
  *  - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE pointers.
- *  - activations are NHWC ("channels-last"): x[b][h][w][c], dense, dtype MRFP_F32 or MRFP_BF16.
+ *  - activations are NHWC ("channels-last"): x[b][h][w][c], dense, dtype MRFP_F32, MRFP_BF16 or MRFP_F16.
  *    Statistics, coefficients, losses and weights' master copies are always fp32.
  *  - the caller allocates every output and every workspace; nothing is allocated, freed or
  *    synchronised inside; every launch goes to `stream` (a hipStream_t passed as void*).
@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-typedef enum { MRFP_F32 = 0, MRFP_BF16 = 1 } mrfp_dtype;
+typedef enum { MRFP_F32 = 0, MRFP_BF16 = 1, MRFP_F16 = 2 } mrfp_dtype;
 
 int mrfp_version(void);
 const char* mrfp_last_error(void);

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mrfp_hip.h")
 LIBPATH = os.path.join(_HERE, "csrc", "libmrfp_hip.so")
 
-F32, BF16 = 0, 1
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
 class MrfpHipError(RuntimeError):
@@ -73,7 +73,7 @@ def dt(t: torch.Tensor) -> int:
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise MrfpHipError("unsupported activation dtype %s (float32 / bfloat16 only)" % t.dtype)
+        raise MrfpHipError("unsupported activation dtype %s (float32 / bfloat16 / float16 only)" % t.dtype)
 
 
 def ptr(t):

@@ -337,6 +337,7 @@ int mrfp_affine_fwd(const void* x, const void* res, void* y, int dtype, int64_t 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MRFP_F32) return launch_affine_fwd<float>(x, res, y, B, Ho, Wo, C, Hs, Ws, tabH, tabW, A, S, coef_per_image, relu, st);
     if (dtype == MRFP_BF16) return launch_affine_fwd<bf16>(x, res, y, B, Ho, Wo, C, Hs, Ws, tabH, tabW, A, S, coef_per_image, relu, st);
+    if (dtype == MRFP_F16) return launch_affine_fwd<f16>(x, res, y, B, Ho, Wo, C, Hs, Ws, tabH, tabW, A, S, coef_per_image, relu, st);
     MRFP_CHECK(false, "affine_fwd: unknown dtype %d", dtype);
 }
 
@@ -351,6 +352,7 @@ int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MRFP_F32) return launch_affine_bwd<float>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
     if (dtype == MRFP_BF16) return launch_affine_bwd<bf16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
+    if (dtype == MRFP_F16) return launch_affine_bwd<f16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
     MRFP_CHECK(false, "affine_bwd: unknown dtype %d", dtype);
 }
 
@@ -359,6 +361,7 @@ int mrfp_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MRFP_F32) return launch_add<float>(a, b, y, n, st);
     if (dtype == MRFP_BF16) return launch_add<bf16>(a, b, y, n, st);
+    if (dtype == MRFP_F16) return launch_add<f16>(a, b, y, n, st);
     MRFP_CHECK(false, "add: unknown dtype %d", dtype);
 }
 

@@ -31,13 +31,16 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 typedef __hip_bfloat16 bf16;
+typedef _Float16 f16;        // IEEE half (MRFP_F16): same 16-byte chunks and MFMA rate as bf16, 11-bit mantissa
 
 // ---- element <-> float ----------------------------------------------------------------------
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16 v) { return __bfloat162float(v); }
+__device__ __forceinline__ float to_f(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __float2bfloat16(v); }
+template <> __device__ __forceinline__ f16 from_f<f16>(float v) { return (f16)v; }
 
 // ---- 16-byte vectors of VEC elements ---------------------------------------------------------
 // VecT<T,VEC>: VEC elements moved with ONE memory instruction when VEC*sizeof(T) == 16

@@ -27,6 +27,7 @@ namespace mrfp {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
 struct ConvP {
     const char* x;      // source activation [B,H,W,C]
@@ -48,6 +49,11 @@ template <> struct Mma<bf16> {
     static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
                                                       acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16> {
+    static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
@@ -105,12 +111,28 @@ template <> __device__ __forceinline__ bf16 chunk_get<bf16>(const uint4& v, int 
     __builtin_memcpy(&r, &h, 2);
     return r;
 }
+template <> __device__ __forceinline__ f16 chunk_get<f16>(const uint4& v, int u) {
+    const unsigned w = (u >> 1) == 0 ? v.x : (u >> 1) == 1 ? v.y : (u >> 1) == 2 ? v.z : v.w;
+    const unsigned short h = (unsigned short)((u & 1) ? (w >> 16) : (w & 0xffffu));
+    f16 r;
+    __builtin_memcpy(&r, &h, 2);
+    return r;
+}
 template <typename T> __device__ __forceinline__ void chunk_set(uint4& v, int u, T x);
 template <> __device__ __forceinline__ void chunk_set<float>(uint4& v, int u, float x) {
     const unsigned w = __float_as_uint(x);
     if (u == 0) v.x = w; else if (u == 1) v.y = w; else if (u == 2) v.z = w; else v.w = w;
 }
 template <> __device__ __forceinline__ void chunk_set<bf16>(uint4& v, int u, bf16 x) {
+    unsigned short h;
+    __builtin_memcpy(&h, &x, 2);
+    const unsigned sh = (u & 1) ? 16u : 0u, mask = ~(0xffffu << sh), bits = (unsigned)h << sh;
+    if ((u >> 1) == 0) v.x = (v.x & mask) | bits;
+    else if ((u >> 1) == 1) v.y = (v.y & mask) | bits;
+    else if ((u >> 1) == 2) v.z = (v.z & mask) | bits;
+    else v.w = (v.w & mask) | bits;
+}
+template <> __device__ __forceinline__ void chunk_set<f16>(uint4& v, int u, f16 x) {
     unsigned short h;
     __builtin_memcpy(&h, &x, 2);
     const unsigned sh = (u & 1) ? 16u : 0u, mask = ~(0xffffu << sh), bits = (unsigned)h << sh;
@@ -581,7 +603,7 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
                "conv_fwd: bad arguments");
     MRFP_CHECK(stride >= 1 && dil >= 1 && sstride >= 1 && ldy >= N, "conv_fwd: bad stride/dilation/pitch");
     const int esz = dtype == MRFP_F32 ? 4 : 2;
-    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "conv_fwd: unknown dtype %d", dtype);
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16 || dtype == MRFP_F16, "conv_fwd: unknown dtype %d", dtype);
     MRFP_CHECK((C * esz) % 16 == 0, "conv_fwd: C=%lld must make 16-byte chunks (pad the channels)", (long long)C);
     MRFP_CHECK(aligned16(x) && aligned16(wpack), "conv_fwd: x / wpack must be 16-byte aligned");
     MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
@@ -600,7 +622,8 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
         if (dbg & 1) p.xbytes = 0;
         if (dbg & 2) p.wbytes = 0;
     }
-    const int rc = dtype == MRFP_F32 ? run_igemm<float>(p, (hipStream_t)stream) : run_igemm<bf16>(p, (hipStream_t)stream);
+    const int rc = dtype == MRFP_F32 ? run_igemm<float>(p, (hipStream_t)stream)
+                   : dtype == MRFP_F16 ? run_igemm<f16>(p, (hipStream_t)stream) : run_igemm<bf16>(p, (hipStream_t)stream);
     if (rc || !colstats) return rc;
     const int64_t nblk = stats_row_blocks(p, esz);
     if (nblk > 2 * kStatGroups) {
@@ -636,6 +659,9 @@ int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, i
     else if (dtype == MRFP_BF16)
         hipLaunchKernelGGL((pack_weight_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
                            (bf16*)wf, (bf16*)wd, (int)N, (int)C, (int)R, (int)S, (int)Npad, (int)Cpad);
+    else if (dtype == MRFP_F16)
+        hipLaunchKernelGGL((pack_weight_kernel<f16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                           (f16*)wf, (f16*)wd, (int)N, (int)C, (int)R, (int)S, (int)Npad, (int)Cpad);
     else
         MRFP_CHECK(false, "pack_weight: unknown dtype %d", dtype);
     MRFP_LAUNCH_CHECK();
@@ -653,6 +679,9 @@ int mrfp_nchw_to_nhwc_pad(const float* x, void* y, int dtype, int64_t B, int64_t
     else if (dtype == MRFP_BF16)
         hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
                            (bf16*)y, (int)B, (int)C, (int)H, (int)W, (int)Cpad);
+    else if (dtype == MRFP_F16)
+        hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<f16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                           (f16*)y, (int)B, (int)C, (int)H, (int)W, (int)Cpad);
     else
         MRFP_CHECK(false, "nchw_to_nhwc_pad: unknown dtype %d", dtype);
     MRFP_LAUNCH_CHECK();
@@ -724,6 +753,7 @@ template <> struct WgFrag<bf16> {
     }
     static constexpr int KSTEP = 16;   // pixels consumed per Mma<bf16>::run
 };
+template <> struct WgFrag<f16> : WgFrag<bf16> {};     // same 16-bit transposing LDS read
 template <> struct WgFrag<float> {
     // 4 MFMA 32x32x2 per call: element j of lane-half h is pixel krow0 + 2*j + h
     static __device__ __forceinline__ uint4 read(const char* tile, int pitch, int col0, int krow0, int lane) {
@@ -956,7 +986,7 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
                     int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, void* stream) {
     MRFP_CHECK(x && dy && dw && ws && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
                "conv_wgrad: bad arguments");
-    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "conv_wgrad: unknown dtype %d", dtype);
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16 || dtype == MRFP_F16, "conv_wgrad: unknown dtype %d", dtype);
     const int esz = dtype == MRFP_F32 ? 4 : 2;
     MRFP_CHECK((C * esz) % 16 == 0 && (ldn * esz) % 16 == 0 && ldn >= N && Ctrue <= C,
                "conv_wgrad: channel counts must make 16-byte chunks (C=%lld ldn=%lld)", (long long)C, (long long)ldn);
@@ -983,6 +1013,7 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st) : launch_wgrad<float, 2, 2>(p, splits, st);
+    else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st) : launch_wgrad<f16, 2, 2>(p, splits, st);
     else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st) : launch_wgrad<bf16, 2, 2>(p, splits, st);
     if (rc) return rc;
     const int64_t total4 = N * (int64_t)p.Q / 4;          // Q = R*S*C and C*esz % 16 == 0  =>  Q % 4 == 0

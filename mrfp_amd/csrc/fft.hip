@@ -507,6 +507,7 @@ int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void*
     p.radius2 = radius * radius; p.lam = lam; p.scale = 1.0f / (float)(H * W); p.high = high; p.load_ratio = load_ratio;
     if (dtype == MRFP_F32) return run_mix<float>(p, (const float2*)twH, (const float2*)twW, (hipStream_t)stream);
     if (dtype == MRFP_BF16) return run_mix<bf16>(p, (const float2*)twH, (const float2*)twW, (hipStream_t)stream);
+    if (dtype == MRFP_F16) return run_mix<f16>(p, (const float2*)twH, (const float2*)twW, (hipStream_t)stream);
     MRFP_CHECK(false, "fourier_mix: unknown dtype %d", dtype);
 }
 

@@ -133,6 +133,8 @@ int mrfp_ce_fwd(const void* logits, const int64_t* target, int dtype, int64_t np
         hipLaunchKernelGGL((ce_fwd_kernel<float>), dim3(nb), dim3(kCeThreads), 0, st, (const float*)logits, target, npix, (int)C, ignore_index, ws);
     else if (dtype == MRFP_BF16)
         hipLaunchKernelGGL((ce_fwd_kernel<bf16>), dim3(nb), dim3(kCeThreads), 0, st, (const bf16*)logits, target, npix, (int)C, ignore_index, ws);
+    else if (dtype == MRFP_F16)
+        hipLaunchKernelGGL((ce_fwd_kernel<f16>), dim3(nb), dim3(kCeThreads), 0, st, (const f16*)logits, target, npix, (int)C, ignore_index, ws);
     else
         MRFP_CHECK(false, "ce_fwd: unknown dtype %d", dtype);
     MRFP_LAUNCH_CHECK();
@@ -150,6 +152,8 @@ int mrfp_ce_bwd(const void* logits, const int64_t* target, const float* loss, co
         hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3(nb), dim3(kCeThreads), 0, st, (const float*)logits, target, loss, gscale, (float*)dlogits, npix, (int)C, ignore_index);
     else if (dtype == MRFP_BF16)
         hipLaunchKernelGGL((ce_bwd_kernel<bf16>), dim3(nb), dim3(kCeThreads), 0, st, (const bf16*)logits, target, loss, gscale, (bf16*)dlogits, npix, (int)C, ignore_index);
+    else if (dtype == MRFP_F16)
+        hipLaunchKernelGGL((ce_bwd_kernel<f16>), dim3(nb), dim3(kCeThreads), 0, st, (const f16*)logits, target, loss, gscale, (f16*)dlogits, npix, (int)C, ignore_index);
     else
         MRFP_CHECK(false, "ce_bwd: unknown dtype %d", dtype);
     MRFP_LAUNCH_CHECK();
@@ -166,6 +170,8 @@ int mrfp_argmax_hist(const void* logits, const int64_t* target, int dtype, int64
         hipLaunchKernelGGL((argmax_hist_kernel<float>), dim3(nb), dim3(kCeThreads), 0, st, (const float*)logits, target, npix, (int)C, (unsigned long long*)hist, pred);
     else if (dtype == MRFP_BF16)
         hipLaunchKernelGGL((argmax_hist_kernel<bf16>), dim3(nb), dim3(kCeThreads), 0, st, (const bf16*)logits, target, npix, (int)C, (unsigned long long*)hist, pred);
+    else if (dtype == MRFP_F16)
+        hipLaunchKernelGGL((argmax_hist_kernel<f16>), dim3(nb), dim3(kCeThreads), 0, st, (const f16*)logits, target, npix, (int)C, (unsigned long long*)hist, pred);
     else
         MRFP_CHECK(false, "argmax_hist: unknown dtype %d", dtype);
     MRFP_LAUNCH_CHECK();
@@ -332,7 +338,7 @@ int mrfp_upsample_ce_fwd(const void* P, int64_t ld, const int64_t* target, int d
     MRFP_CHECK(P && target && ws && loss && B > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0 && C > 0 && C <= mrfp::kMaxClasses,
                "upsample_ce_fwd: bad arguments");
     const int esz = dtype == MRFP_F32 ? 4 : 2, epc = 16 / esz;
-    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "upsample_ce_fwd: unknown dtype %d", dtype);
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16 || dtype == MRFP_F16, "upsample_ce_fwd: unknown dtype %d", dtype);
     MRFP_CHECK(ld % epc == 0 && ld >= (C + epc - 1) / epc * epc && mrfp::aligned16(P),
                "upsample_ce_fwd: the score buffer must be channel-padded to 16-byte chunks (ld=%lld)", (long long)ld);
     hipStream_t st = (hipStream_t)stream;
@@ -340,6 +346,7 @@ int mrfp_upsample_ce_fwd(const void* P, int64_t ld, const int64_t* target, int d
     mrfp::UpCeArgs a{P, (int)ld, target, nullptr, nullptr, nullptr, 0, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
                      ignore_index, ws, nb, st};
     if (dtype == MRFP_F32) mrfp::dispatch_up_ce<float>(a, false);
+    else if (dtype == MRFP_F16) mrfp::dispatch_up_ce<mrfp::f16>(a, false);
     else mrfp::dispatch_up_ce<mrfp::bf16>(a, false);
     MRFP_LAUNCH_CHECK();
     hipLaunchKernelGGL(mrfp::ce_finalize_kernel, dim3(1), dim3(256), 0, st, ws, nb, loss);
@@ -353,7 +360,7 @@ int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const
     MRFP_CHECK(P && target && loss && dlogits && B > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0 && C > 0 && C <= mrfp::kMaxClasses,
                "upsample_ce_bwd: bad arguments");
     const int esz = dtype == MRFP_F32 ? 4 : 2, epc = 16 / esz;
-    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16, "upsample_ce_bwd: unknown dtype %d", dtype);
+    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16 || dtype == MRFP_F16, "upsample_ce_bwd: unknown dtype %d", dtype);
     MRFP_CHECK(ld % epc == 0 && Cd % epc == 0 && Cd >= C && ld >= Cd && mrfp::aligned16(P) && mrfp::aligned16(dlogits),
                "upsample_ce_bwd: channel pitches must be 16-byte multiples (ld=%lld Cd=%lld)", (long long)ld, (long long)Cd);
     hipStream_t st = (hipStream_t)stream;
@@ -361,6 +368,7 @@ int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const
     mrfp::UpCeArgs a{P, (int)ld, target, loss, gscale, dlogits, (int)Cd, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
                      ignore_index, nullptr, nb, st};
     if (dtype == MRFP_F32) mrfp::dispatch_up_ce<float>(a, true);
+    else if (dtype == MRFP_F16) mrfp::dispatch_up_ce<mrfp::f16>(a, true);
     else mrfp::dispatch_up_ce<mrfp::bf16>(a, true);
     MRFP_LAUNCH_CHECK();
     return 0;

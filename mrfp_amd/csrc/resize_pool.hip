@@ -319,6 +319,7 @@ int mrfp_bilinear_fwd(const void* x, const void* addend, void* y, int dtype, int
     MRFP_CHECK(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && ld_in >= C, "bilinear_fwd: bad arguments");
     if (dtype == MRFP_F32) return do_bilinear_fwd<float>(x, addend, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
     if (dtype == MRFP_BF16) return do_bilinear_fwd<bf16>(x, addend, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
+    if (dtype == MRFP_F16) return do_bilinear_fwd<f16>(x, addend, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
     MRFP_CHECK(false, "bilinear_fwd: unknown dtype %d", dtype);
 }
 int mrfp_bilinear_bwd(const void* dy, void* dx, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
@@ -326,6 +327,7 @@ int mrfp_bilinear_bwd(const void* dy, void* dx, int dtype, int64_t B, int64_t Hi
     MRFP_CHECK(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && ld_in >= C, "bilinear_bwd: bad arguments");
     if (dtype == MRFP_F32) return do_bilinear_bwd<float>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
     if (dtype == MRFP_BF16) return do_bilinear_bwd<bf16>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
+    if (dtype == MRFP_F16) return do_bilinear_bwd<f16>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
     MRFP_CHECK(false, "bilinear_bwd: unknown dtype %d", dtype);
 }
 int mrfp_maxpool_fwd(const void* x, void* y, uint8_t* idx, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
@@ -333,6 +335,7 @@ int mrfp_maxpool_fwd(const void* x, void* y, uint8_t* idx, int dtype, int64_t B,
     MRFP_CHECK(x && y && idx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_fwd: bad arguments");
     if (dtype == MRFP_F32) return do_maxpool_fwd<float>(x, y, idx, B, H, W, C, (hipStream_t)stream);
     if (dtype == MRFP_BF16) return do_maxpool_fwd<bf16>(x, y, idx, B, H, W, C, (hipStream_t)stream);
+    if (dtype == MRFP_F16) return do_maxpool_fwd<f16>(x, y, idx, B, H, W, C, (hipStream_t)stream);
     MRFP_CHECK(false, "maxpool_fwd: unknown dtype %d", dtype);
 }
 int mrfp_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int64_t B, int64_t H, int64_t W,
@@ -340,6 +343,7 @@ int mrfp_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, in
     MRFP_CHECK(dy && dx && idx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd: bad arguments");
     if (dtype == MRFP_F32) return do_maxpool_bwd<float>(dy, idx, dx, B, H, W, C, (hipStream_t)stream);
     if (dtype == MRFP_BF16) return do_maxpool_bwd<bf16>(dy, idx, dx, B, H, W, C, (hipStream_t)stream);
+    if (dtype == MRFP_F16) return do_maxpool_bwd<f16>(dy, idx, dx, B, H, W, C, (hipStream_t)stream);
     MRFP_CHECK(false, "maxpool_bwd: unknown dtype %d", dtype);
 }
 

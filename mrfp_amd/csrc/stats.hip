@@ -445,6 +445,7 @@ int mrfp_stats_fwd(const void* x, int dtype, int64_t B, int64_t Ho, int64_t Wo, 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MRFP_F32) return launch_stats<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     if (dtype == MRFP_BF16) return launch_stats<bf16, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_F16) return launch_stats<f16, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     MRFP_CHECK(false, "stats_fwd: unknown dtype %d", dtype);
 }
 
@@ -456,6 +457,7 @@ int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* me
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MRFP_F32) return launch_stats<float, 1>(x, dy, y, mean, fA, fS, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     if (dtype == MRFP_BF16) return launch_stats<bf16, 1>(x, dy, y, mean, fA, fS, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
+    if (dtype == MRFP_F16) return launch_stats<f16, 1>(x, dy, y, mean, fA, fS, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     MRFP_CHECK(false, "stats_bwd: unknown dtype %d", dtype);
 }
 
@@ -545,6 +547,10 @@ int mrfp_mean_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count,
     if (dtype == MRFP_BF16) {
         const int64_t n = B * C;
         hipLaunchKernelGGL((cast_out_kernel<bf16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, (bf16*)out, n);
+        MRFP_LAUNCH_CHECK();
+    } else if (dtype == MRFP_F16) {
+        const int64_t n = B * C;
+        hipLaunchKernelGGL((cast_out_kernel<f16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, (f16*)out, n);
         MRFP_LAUNCH_CHECK();
     } else {
         MRFP_CHECK(dtype == MRFP_F32, "mean_finalize: unknown dtype %d", dtype);

@@ -175,18 +175,30 @@ class GradSync:
 class Trainer:
     """zero_grad -> forward -> backward (+ overlapped all-reduce) -> fused SGD step -> LR step."""
 
-    def __init__(self, model, lr=1e-2, momentum=0.9, weight_decay=5e-4, max_iter=40000, bucket_mb=32.0):
+    def __init__(self, model, lr=1e-2, momentum=0.9, weight_decay=5e-4, max_iter=40000, bucket_mb=32.0,
+                 loss_scale=None):
+        """loss_scale: static scale of the backward pass for float16 activations (the per-pixel CE gradient is
+        1/#pixels ~ 1e-7, below float16's normal range); default 65536 when cfg.MODEL.ACT_DTYPE is float16, else 1.
+        The scale enters through the gradient of the loss (the CE backward kernel multiplies by it) and leaves in the
+        fused SGD kernel's gradient scale, so parameters see exactly the unscaled step."""
+        from .config import cfg
         self.model = model
         self.opt = FlatSGD(model, lr, momentum, weight_decay, max_iter)
         self.sync = GradSync(self.opt, bucket_mb)
+        if loss_scale is None:
+            loss_scale = 65536.0 if cfg.MODEL.ACT_DTYPE == torch.float16 else 1.0
+        self.loss_scale = float(loss_scale)
 
     def step(self, img, label):
         self.opt.zero_grad()
         self.sync.begin()
         loss = self.model(img, label, training=True)
-        loss.backward()
+        if self.loss_scale != 1.0:
+            loss.backward(torch.full_like(loss, self.loss_scale))
+        else:
+            loss.backward()
         gscale = self.sync.finish()
-        self.opt.step(gscale)
+        self.opt.step(gscale / self.loss_scale)
         return loss
 
 
