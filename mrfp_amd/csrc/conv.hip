@@ -729,6 +729,7 @@ struct WgP {
     int R, S, Ho, Wo, stride, pad_h, pad_w, dil;
     int M, Q;         // pixels, R*S*C
     int klen;         // pixels per split (multiple of the K' tile)
+    int tiles;        // output tiles per split
     unsigned xbytes, dybytes;
     FastDiv div_hw, div_w;   // by Ho*Wo and by Wo
 };
@@ -786,8 +787,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntq = (p.Q + 64 * WN - 1) / (64 * WN);
-    const int n0 = (blockIdx.x / ntq) * 64 * WM, q0 = (blockIdx.x % ntq) * 64 * WN;
-    const int kbeg = blockIdx.y * p.klen;
+    // 1-D grid over (split, tile), split-major, dealt to the XCDs in contiguous chunks: the tiles of one split read the
+    // same pixel range of x and dy, so they share one L2 instead of pulling those rows into all eight
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = work / p.tiles, tile = work - split * p.tiles;
+    const int n0 = (tile / ntq) * 64 * WM, q0 = (tile % ntq) * 64 * WN;
+    const int kbeg = split * p.klen;
     const int kend = min(p.M, kbeg + p.klen);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dybytes, 0x00020000);
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
         __syncthreads();
     }
 
-    float* out = p.slab + (size_t)blockIdx.y * p.N * p.Q;
+    float* out = p.slab + (size_t)split * p.N * p.Q;
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -943,8 +948,9 @@ static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int tiles = ((p.N + 64 * WM - 1) / (64 * WM)) * ((p.Q + 64 * WN - 1) / (64 * WN));
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, p);
+    WgP q = p;
+    q.tiles = ((p.N + 64 * WM - 1) / (64 * WM)) * ((p.Q + 64 * WN - 1) / (64 * WN));
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN>), dim3((unsigned)(q.tiles * splits)), dim3(256), lds, st, q);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
