@@ -960,14 +960,30 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& s
     const int wn = 4 / wm;
     const int64_t tiles = ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
     const int64_t nkt = (M + bkp - 1) / bkp;
-    static int target = 0;        // workgroups to aim for (MRFP_WGRAD_WGS for A/B runs).  Measured in the bench workload:
-                                  // 384 / 512 / 768 / 1024 -> 46.9 / 46.3 / 46.9 / 48.2 ms of convolutions per step
-    if (target == 0) {
+    // Split count from a small cost model (times in us, constants fitted to the bench workload's per-launch timings):
+    //   a CU that holds w = ceil(tiles*sp/256) workgroups needs w * (K' tiles per split) tile-steps of ~0.84 us, divided
+    //   by a latency-hiding efficiency (1 workgroup per CU 0.6, 2 -> 0.85, >= 3 -> 1); every split adds an fp32 slab of dW
+    //   that is written once and read once by the reduction (~3 TB/s).
+    // MRFP_WGRAD_WGS=<n> replaces the model by "about n workgroups" (A/B measurements).
+    static int target = -1;
+    if (target < 0) {
         const char* e = getenv("MRFP_WGRAD_WGS");
-        target = e ? atoi(e) : 512;
-        if (target < 64) target = 512;
+        target = e ? atoi(e) : 0;
     }
-    int64_t sp = target / tiles;  // every extra split costs an fp32 slab of the whole dW
+    int64_t sp = 1;
+    if (target > 0) {
+        sp = target / tiles;
+    } else {
+        double best = 1e30;
+        int64_t smax = 1024 / tiles > 96 ? 1024 / tiles : 96;      // few tiles: enough splits to fill the chip
+        if (smax > nkt) smax = nkt;
+        for (int64_t c = 1; c <= smax; ++c) {
+            const int64_t w = (tiles * c + 255) / 256, iters = (nkt + c - 1) / c;
+            const double eff = w >= 3 ? 1.0 : w == 2 ? 0.85 : 0.6;
+            const double cost = (double)w * (double)iters * 0.84 / eff + (double)c * ((double)N * (double)Q * 8.0 / 3.0e6);
+            if (cost < best * 0.999) { best = cost; sp = c; }
+        }
+    }
     if (sp < 1) sp = 1;
     if (sp > nkt) sp = nkt;
     int64_t per = (nkt + sp - 1) / sp;        // K' tiles per split
