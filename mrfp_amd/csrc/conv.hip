@@ -418,6 +418,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
 // Folds the per-row-block statistics [nblk][2][C] of a forward launch into kStatGroups rows (appended after row
 // nblk) so that the BatchNorm finalize kernel walks 64 partials per channel instead of thousands.
 constexpr int kStatGroups = 64;
+// up to this many row blocks the BatchNorm finalize kernel (8 channels x 128 partial lanes per workgroup) walks the
+// partials itself; a separate compaction launch costs ~5 us whatever it does
+constexpr int kCompactAbove = 2048;
 __global__ __launch_bounds__(256) void compact_stats_kernel(float* __restrict__ st, int nblk, int C2) {   // C2 = 2*C floats per row
     // block = 64 columns x 4 row quarters (fixed split and fixed order: bitwise reproducible)
     __shared__ float part[4][64];
@@ -575,6 +578,49 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// All weight packs of a model in ONE launch (after the optimizer step): jobs[] and the exclusive prefix of their element
+// counts live in device memory; every thread finds its job by binary search and packs one element as above.
+struct PackJob {
+    const float* w;
+    void* wf;
+    void* wd;
+    int N, C, R, S, Npad, Cpad;
+};
+template <typename T>
+__global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int64_t* __restrict__ prefix, int njobs,
+                                            int64_t total) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = njobs;                 // largest j with prefix[j] <= g
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= g) lo = mid; else hi = mid;
+        }
+        const PackJob jb = jobs[lo];
+        const int64_t i = g - prefix[lo];
+        const int N = jb.N, C = jb.C, R = jb.R, S = jb.S, Npad = jb.Npad, Cpad = jb.Cpad;
+        const int64_t nf = (int64_t)Npad * R * S * Cpad;
+        const float* w = jb.w;
+        if (i < nf) {
+            const int c = (int)(i % Cpad);
+            int64_t rest = i / Cpad;
+            const int s2 = (int)(rest % S); rest /= S;
+            const int r = (int)(rest % R);
+            const int n = (int)(rest / R);
+            const float v = (n < N && c < C) ? w[(((int64_t)n * C + c) * R + r) * S + s2] : 0.f;
+            reinterpret_cast<T*>(jb.wf)[i] = from_f<T>(v);
+        } else {
+            const int64_t k = i - nf;
+            const int n = (int)(k % Npad);
+            int64_t rest = k / Npad;
+            const int s2 = (int)(rest % S); rest /= S;
+            const int r = (int)(rest % R);
+            const int c = (int)(rest / R);
+            const float v = (n < N) ? w[(((int64_t)n * C + c) * R + (R - 1 - r)) * S + (S - 1 - s2)] : 0.f;
+            reinterpret_cast<T*>(jb.wd)[k] = from_f<T>(v);
+        }
+    }
+}
+
 // network input: NCHW fp32 [B,C,H,W] -> NHWC T [B,H,W,Cpad] (pad channels zero)
 template <typename T>
 __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int H, int W, int Cpad) {
@@ -626,7 +672,7 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
                    : dtype == MRFP_F16 ? run_igemm<f16>(p, (hipStream_t)stream) : run_igemm<bf16>(p, (hipStream_t)stream);
     if (rc || !colstats) return rc;
     const int64_t nblk = stats_row_blocks(p, esz);
-    if (nblk > 2 * kStatGroups) {
+    if (nblk > kCompactAbove) {
         const int C2 = 2 * (int)ldy;
         hipLaunchKernelGGL(compact_stats_kernel, dim3((unsigned)((C2 + 63) / 64), kStatGroups), dim3(256), 0,
                            (hipStream_t)stream, colstats, (int)nblk, C2);
@@ -642,10 +688,10 @@ int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64
     return stats_row_blocks(p, esz);
 }
 /* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */
-int64_t mrfp_conv_stats_rows(int64_t nblk) { return nblk > 2 * kStatGroups ? nblk + kStatGroups : nblk; }
+int64_t mrfp_conv_stats_rows(int64_t nblk) { return nblk > kCompactAbove ? nblk + kStatGroups : nblk; }
 /* where the rows to hand to mrfp_bn_finalize start, and how many there are */
-int64_t mrfp_conv_stats_final_first(int64_t nblk) { return nblk > 2 * kStatGroups ? nblk : 0; }
-int64_t mrfp_conv_stats_final_count(int64_t nblk) { return nblk > 2 * kStatGroups ? kStatGroups : nblk; }
+int64_t mrfp_conv_stats_final_first(int64_t nblk) { return nblk > kCompactAbove ? nblk : 0; }
+int64_t mrfp_conv_stats_final_count(int64_t nblk) { return nblk > kCompactAbove ? kStatGroups : nblk; }
 
 int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, int64_t C, int64_t R, int64_t S,
                      int64_t Npad, int64_t Cpad, void* stream) {
@@ -664,6 +710,23 @@ int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, i
                            (f16*)wf, (f16*)wd, (int)N, (int)C, (int)R, (int)S, (int)Npad, (int)Cpad);
     else
         MRFP_CHECK(false, "pack_weight: unknown dtype %d", dtype);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_pack_weights_batched(const void* jobs, const int64_t* prefix, int64_t njobs, int64_t total, int dtype, void* stream) {
+    MRFP_CHECK(jobs && prefix && njobs > 0 && total > 0, "pack_weights_batched: bad arguments");
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const mrfp::PackJob* jb = (const mrfp::PackJob*)jobs;
+    if (dtype == MRFP_F32)
+        hipLaunchKernelGGL((pack_weights_batched_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jb, prefix, (int)njobs, total);
+    else if (dtype == MRFP_BF16)
+        hipLaunchKernelGGL((pack_weights_batched_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jb, prefix, (int)njobs, total);
+    else if (dtype == MRFP_F16)
+        hipLaunchKernelGGL((pack_weights_batched_kernel<f16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jb, prefix, (int)njobs, total);
+    else
+        MRFP_CHECK(false, "pack_weights_batched: unknown dtype %d", dtype);
     MRFP_LAUNCH_CHECK();
     return 0;
 }

@@ -166,7 +166,8 @@ struct Red { double s, q; };
 
 // block = (kFC channels) x (kFL partial lanes): few channels per block so that even a 64-channel layer
 // spreads over 8 workgroups, many lanes so that every thread only walks n/kFL partials (all independent loads).
-constexpr int kFC = 8, kFL = 32;
+constexpr int kFC = 8, kFL = 128;      // 1024 threads: 2048 partial rows = 16 per thread = 4 batches of independent loads
+constexpr int kFold = 8;                // lanes folded per thread in the first level of the final sum
 __device__ __forceinline__ Red reduce_partials(const float* ws, int64_t first, int64_t n, int64_t C, int c, bool valid,
                                                double (*sm)[2][kFC]) {
     const int ty = threadIdx.y, tx = threadIdx.x;
@@ -192,10 +193,19 @@ __device__ __forceinline__ Red reduce_partials(const float* ws, int64_t first, i
     sm[ty][0][tx] = s;
     sm[ty][1][tx] = q;
     __syncthreads();
+    // two-level sum in a fixed order: kFL/kFold lanes fold kFold entries each, lane 0 folds those
+    double s1 = 0.0, q1 = 0.0;
+    if (ty < kFL / kFold) {
+#pragma unroll
+        for (int k = 0; k < kFold; ++k) { s1 += sm[ty * kFold + k][0][tx]; q1 += sm[ty * kFold + k][1][tx]; }
+    }
+    __syncthreads();
+    if (ty < kFL / kFold) { sm[ty][0][tx] = s1; sm[ty][1][tx] = q1; }
+    __syncthreads();
     Red r{0.0, 0.0};
     if (ty == 0) {
 #pragma unroll
-        for (int k = 0; k < kFL; ++k) { r.s += sm[k][0][tx]; r.q += sm[k][1][tx]; }
+        for (int k = 0; k < kFL / kFold; ++k) { r.s += sm[k][0][tx]; r.q += sm[k][1][tx]; }
     }
     return r;
 }

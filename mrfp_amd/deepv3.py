@@ -40,9 +40,11 @@ class ReferenceRandom:
             initialize_weights_kaimingnormal_forOC(bn)
 
     def np_noise(self, which, B, C, device):
-        ones = torch.ones(B, C, 1, 1, device=device)
-        alpha = torch.normal(ones, 0.75 * ones)
-        beta_noise = torch.normal(torch.zeros_like(ones), 0.75 * ones)
+        # torch.normal(mean_tensor, std_tensor) as the reference calls it (deepv3.py:274-275) is, inside ATen,
+        # normal_(0, 1).mul_(std).add_(mean) preceded by a host-synchronising check std.min() >= 0; the same draws
+        # (same generator consumption) without the two device->host round trips per call:
+        alpha = torch.randn(B, C, 1, 1, device=device).mul_(0.75).add_(1.0)
+        beta_noise = torch.randn(B, C, 1, 1, device=device).mul_(0.75)
         return alpha, beta_noise
 
 

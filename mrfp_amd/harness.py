@@ -82,6 +82,7 @@ class FlatSGD(FlatArena):
         # weight packs explicitly (mrfp_amd/conv.py rebuilds them on next use)
         from . import conv
         conv.invalidate_packs()
+        conv.repack_all()                             # one launch for every bias-free trainable pack
         self.it += 1                                  # scheduler.step()
 
 

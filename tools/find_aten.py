@@ -32,8 +32,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
     dt = getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)
-    if e.key.startswith("aten::") and dt > 20:
+    if e.key.startswith("aten::") and (dt > 20 or (len(sys.argv) > 1 and e.count >= 8)):
         rows.append((dt, e.key, e.count, str(e.input_shapes)[:150]))
 rows.sort(reverse=True)
-for dt, k, c, sh in rows[:60]:
+for dt, k, c, sh in (rows if len(sys.argv) > 2 else rows[:60]):
     print("%9.1f us  x%-4d %-28s %s" % (dt, c, k, sh))
