@@ -276,13 +276,13 @@ static int launch_affine_bwd(const void* dy, const void* x, const void* y, void*
     const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(dy) && aligned16(dx) && (!x || aligned16(x)) &&
                         (!y || aligned16(y)) && (!dres || aligned16(dres)) && (!P || aligned16(P)) &&
                         (!Q || aligned16(Q)) && (!R || aligned16(R)) && (!fA || (aligned16(fA) && aligned16(fS)));
-    // fan-in bound of a nearest resize: at most ceil(out/in) destinations per source and axis (+1 for the float
-    // rounding of ATen's index rule); the kernel checks the exact count per pixel and falls back to plain loops
+    // fan-in of a nearest resize: ceil(out/in) destinations per source and axis (one more can appear through the float
+    // rounding of ATen's index rule: the kernel checks the exact count per pixel and takes the plain loops for those)
     int kr = 0;
     if (invH && invW && !y && !dres) {
-        const int64_t kh = (Ho + Hs - 1) / Hs + 1, kw = (Wo + Ws - 1) / Ws + 1;
+        const int64_t kh = (Ho + Hs - 1) / Hs, kw = (Wo + Ws - 1) / Ws;
         const int64_t k = kh > kw ? kh : kw;
-        kr = k <= 2 ? 2 : k <= 3 ? 3 : 0;
+        kr = k <= 3 ? (int)k : 0;
     }
 #define MRFP_AFFB_LAUNCH(VECV, KRV)                                                                                    \
     hipLaunchKernelGGL((affine_bwd_kernel<T, VECV, KRV>), grid, dim3(kThreads), 0, st, (const T*)dy, (const T*)x,      \
@@ -290,11 +290,13 @@ static int launch_affine_bwd(const void* dy, const void* x, const void* y, void*
     const bool identity = !invH && !invW;
     if (vec_ok) {
         if (identity) MRFP_AFFB_LAUNCH(FullVec<T>::value, -1);
+        else if (kr == 1) MRFP_AFFB_LAUNCH(FullVec<T>::value, 1);
         else if (kr == 2) MRFP_AFFB_LAUNCH(FullVec<T>::value, 2);
         else if (kr == 3) MRFP_AFFB_LAUNCH(FullVec<T>::value, 3);
         else MRFP_AFFB_LAUNCH(FullVec<T>::value, 0);
     } else {
         if (identity) MRFP_AFFB_LAUNCH(1, -1);
+        else if (kr == 1) MRFP_AFFB_LAUNCH(1, 1);
         else if (kr == 2) MRFP_AFFB_LAUNCH(1, 2);
         else if (kr == 3) MRFP_AFFB_LAUNCH(1, 3);
         else MRFP_AFFB_LAUNCH(1, 0);
