@@ -199,6 +199,9 @@ class _BatchNormAct(torch.autograd.Function):
         else:
             call("mrfp_bn_eval_coef", C, ptr(w32), ptr(b32), ptr(running_mean), ptr(running_var), float(eps),
                  ptr(A), ptr(S), stream())
+            if x.requires_grad or (weight is not None and weight.requires_grad):
+                mean.copy_(running_mean)                          # what the backward's x-hat is built from
+                torch.rsqrt(running_var.float() + eps, out=invstd)
         y = _affine_fwd(x, res, A, S, False, relu, plan)
         ctx.plan, ctx.relu, ctx.training, ctx.has_res = plan, relu, training, res is not None
         # ReLU mask for backward: without a residual it is recomputed from x and the apply coefficients
@@ -213,8 +216,6 @@ class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, w32, mean, invstd, A, S = ctx.saved_tensors
-        if not ctx.training:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not on the MRFP hot path")
         dy = _chk(dy, "dy")
         plan = ctx.plan
         B, Ho, Wo, C, *_ = _geom(x, plan)
@@ -226,6 +227,11 @@ class _BatchNormAct(torch.autograd.Function):
         sb = grad_sink(ctx.bparam) if ctx.needs_input_grad[2] else None
         call("mrfp_bn_bwd_finalize", ptr(ws), B, nslab, B * Ho * Wo, C, ptr(w32), ptr(mean), ptr(invstd),
              ptr(sw if sw is not None else dw), ptr(sb if sb is not None else db), ptr(P), ptr(Q), ptr(R), stream())
+        if not ctx.training:
+            # module in eval mode (running statistics are constants): the same dweight / dbias sums, but the input
+            # gradient is just dy' * weight * invstd -- the batch-statistics terms Q, R vanish
+            Q.zero_()
+            R.zero_()
         dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x, fA, fS)
         if sw is not None:
             notify_grad(ctx.wparam)

@@ -88,6 +88,17 @@ def test_batch_norm_act(dtype, shape, relu, res):
     ye = o.batch_norm_act(xd.detach(), wd.detach(), bd.detach(), rm_d, rv_d, training=False, relu=relu)
     yec = F.batch_norm(x, rm_c, rv_c, w, b, False, 0.1, 1e-5)
     assert relerr(ye, F.relu(yec) if relu else yec) < t
+    # eval mode backward (module in eval(), training=True argument: reference deepv3.py keys the two separately)
+    xe = dev(x, dtype)
+    we, be = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    ye = o.batch_norm_act(xe, we, be, rm_d, rv_d, training=False, relu=relu)
+    ye.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    xc2 = x.clone().requires_grad_(True)
+    wc2, bc2 = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yc2 = F.batch_norm(xc2, rm_c, rv_c, wc2, bc2, False, 0.1, 1e-5)
+    (F.relu(yc2) if relu else yc2).backward(gy)
+    assert relerr(xe.grad, xc2.grad) < 10 * t
+    assert relerr(we.grad, wc2.grad) < 10 * t and relerr(be.grad, bc2.grad) < 10 * t
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
