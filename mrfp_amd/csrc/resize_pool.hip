@@ -177,19 +177,30 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restri
                 uint8_t bi[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+                // the 9 window loads are unconditional (clamped coordinates, all in flight together); positions outside
+                // the image are skipped in the comparison, so the first-maximum rule of ATen is unchanged
+                VecT<T, VEC> win[9];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int ih = min(max(2 * oh - 1 + r, 0), H - 1);
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const int iw = min(max(2 * ow - 1 + s, 0), W - 1);
+                        win[r * 3 + s] = load_raw<T, VEC>(x + (((size_t)b * H + ih) * W + iw) * C + (size_t)cv * VEC);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int ih = 2 * oh - 1 + r;
-                    if (ih < 0 || ih >= H) continue;
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
                         const int iw = 2 * ow - 1 + s;
-                        if (iw < 0 || iw >= W) continue;
+                        const bool inside = ih >= 0 && ih < H && iw >= 0 && iw < W;
                         float v[VEC];
-                        load_f<T, VEC>(x + (((size_t)b * H + ih) * W + iw) * C + (size_t)cv * VEC, v);
+                        cvt_f<T, VEC>(win[r * 3 + s], v);
 #pragma unroll
                         for (int i = 0; i < VEC; ++i)
-                            if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bi[i] = (uint8_t)(r * 3 + s); }
+                            if (inside && (v[i] > best[i] || v[i] != v[i])) { best[i] = v[i]; bi[i] = (uint8_t)(r * 3 + s); }
                     }
                 }
                 const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C + (size_t)cv * VEC;
@@ -220,21 +231,30 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
                 float acc[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-                for (int oh = oh0; oh <= oh1; ++oh) {
-                    if (oh >= Ho) continue;
-                    const int r = ih - (2 * oh - 1);
-                    for (int ow = ow0; ow <= ow1; ++ow) {
-                        if (ow >= Wo) continue;
-                        const int s = iw - (2 * ow - 1);
-                        const uint8_t want = (uint8_t)(r * 3 + s);
-                        const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C + (size_t)cv * VEC;
-                        const VecT<uint8_t, VEC> pk = *reinterpret_cast<const VecT<uint8_t, VEC>*>(idx + o);
-                        float dv[VEC];
-                        load_f<T, VEC>(dy + o, dv);
+                // at most 2 x 2 windows contain this pixel: 4 unconditional (clamped) gradient + index loads
+                VecT<T, VEC> dr[4];
+                VecT<uint8_t, VEC> pk[4];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) acc[i] += pk.v[i] == want ? dv[i] : 0.f;
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const int oh = min(oh0 + a, Ho - 1), ow = min(ow0 + c2, Wo - 1);
+                        const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C + (size_t)cv * VEC;
+                        pk[a * 2 + c2] = *reinterpret_cast<const VecT<uint8_t, VEC>*>(idx + o);
+                        dr[a * 2 + c2] = load_raw<T, VEC>(dy + o);
                     }
-                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const int oh = oh0 + a, ow = ow0 + c2;
+                        const bool have = oh <= oh1 && oh < Ho && ow <= ow1 && ow < Wo;
+                        const uint8_t want = (uint8_t)((ih - (2 * oh - 1)) * 3 + (iw - (2 * ow - 1)));
+                        float dv[VEC];
+                        cvt_f<T, VEC>(dr[a * 2 + c2], dv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] += (have && pk[a * 2 + c2].v[i] == want) ? dv[i] : 0.f;
+                    }
                 store_f<T, VEC>(dx + (((size_t)b * H + ih) * W + iw) * C + (size_t)cv * VEC, acc);
             }
         }
