@@ -541,7 +541,8 @@ static int run_igemm(const ConvP& p, hipStream_t st) {
     // layers (fill / drain dominate) and on N that wastes most of the second 256-column tile; a 256x128
     // 4-wave variant (254 VGPRs) lost 25 % everywhere and was dropped.
     if (use_big_tile(p, (int)sizeof(T))) return pick_igemm<T, 2, 4, 4, 2>(p, st);
-    // (a two-wave 96x128 variant, 2 x (96x64), 216 registers, fewer LDS reads per MFMA, measured 5-25 % slower)
+    // (measured and dropped: a two-wave 96x128 variant, 2 x (96x64), 216 registers, fewer LDS reads per MFMA: 5-25 %
+    //  slower; a 256x128 8-wave LDS-DMA tile for the N = 128 layers: 753 vs 803 TF/s at 16x384x384x256 -> 128)
     if (use_tile96(p, (int)sizeof(T))) return pick_igemm<T, 1, 4, 3, 1>(p, st);
     return pick_igemm<T, 2, 2, 2, 2>(p, st);
 }

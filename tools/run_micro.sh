@@ -1,6 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for s in l3_3x3 l3_1x1 l3_exp; do
-for v in "MRFP_CONV_T96W=4" "MRFP_CONV_T96W=2"; do
-echo "== $s $v"; env $v python3 $R/tools/conv_micro.py $s 30 fwd 2>&1 | tail -1
-done; done
+for v in "MRFP_CONV_T256X128=0" "MRFP_CONV_T256X128=1"; do
+echo "== hrfp128 $v"; env $v python3 $R/tools/conv_micro.py hrfp128 20 fwd 2>&1 | tail -1
+done
