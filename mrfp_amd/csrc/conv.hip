@@ -150,7 +150,6 @@ template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a,
 
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
-    static_assert(!DMA || NBUF == 2, "LDS-DMA staging needs two LDS buffers");
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -298,7 +297,16 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
                 for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
     };
-    if (DMA) {
+    if (DMA && NBUF == 1) {
+        // single LDS buffer filled by LDS-DMA: no register staging and no ds_write at all; the fill latency of a
+        // workgroup is exposed and hidden only by the other workgroups of the CU (more of them fit: fewer registers)
+        for (int kt = 0; kt < nkt; ++kt) {
+            load_tile(kt, ra, rb, 0);
+            __syncthreads();          // vmcnt(0) + barrier: the tile has landed
+            compute(0);
+            __syncthreads();          // everybody is done reading before the next fill
+        }
+    } else if (DMA) {
         // tile k+1 streams into the other LDS buffer while tile k is multiplied; __syncthreads() = vmcnt(0) (this
         // wave's DMA pieces have landed) + barrier (so have everybody else's, and everybody is done reading tile k)
         load_tile(0, ra, rb, 0);
@@ -473,12 +481,19 @@ static int launch_igemm(const ConvP& p, hipStream_t st) {
         g_nbuf = e ? atoi(e) : 1;
         if (g_nbuf != 2) g_nbuf = 1;   // default (measured on MI355X): single buffer, 3 workgroups per CU
     }
-    static int dma = -1;      // MRFP_CONV_DMA: 0 = register staging everywhere, 1 = LDS-DMA for the 128x64-per-wave tiles
-    if (dma < 0) {            //               2 = LDS-DMA for every tile shape
+    // MRFP_CONV_DMA (A/B measurements): 0 = register staging everywhere; 1 = LDS-DMA (two buffers) for the 8-wave tile
+    // only; 2 = LDS-DMA with two buffers everywhere; 3 (default) = LDS-DMA everywhere, ONE buffer for the 4-wave tiles
+    // (no staging registers, no ds_write: 112 / 90 registers -> 4-5 workgroups per CU hide each other's fill latency;
+    // measured against mode 1: M = 36 864 3x3 layers 630 -> 792 TF/s, 128x128 tile 844 -> 919, fwd+dgrad 31.8 -> 30.0 ms
+    // per step) and two for the 8-wave tile (one buffer there: 902 -> 862); 4 = one buffer everywhere.
+    static int dma = -1;
+    if (dma < 0) {
         const char* e = getenv("MRFP_CONV_DMA");
-        dma = e ? atoi(e) : 1;
+        dma = e ? atoi(e) : 3;
     }
     if ((dma == 1 && TM * TN >= 8) || dma == 2) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
+    if ((dma == 3 && TM * TN < 8) || dma == 4) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, true>(p, st);
+    if (dma == 3) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
     if (TM * TN >= 8 || g_nbuf == 1) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, false>(p, st);
     return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, false>(p, st);
 }
