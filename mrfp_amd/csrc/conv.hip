@@ -835,6 +835,25 @@ template <> struct WgFrag<bf16> {
     static constexpr int KSTEP = 16;   // pixels consumed per Mma<bf16>::run
 };
 template <> struct WgFrag<f16> : WgFrag<bf16> {};     // same 16-bit transposing LDS read
+
+// LDS-DMA tile layout of the 16-bit wgrad operands: rows of NB 64-byte blocks with NO padding (a DMA piece is 1 KiB of
+// contiguous LDS); block lb of row r sits at physical block lb ^ key(r), key = r & 3 (NB >= 4) or (r >> 1) & 1 (NB == 2),
+// so that the four pixel rows of one transposing read still fall into four disjoint 64-byte bank windows.
+template <int NB> __device__ __forceinline__ int wg_key(int row) { return NB >= 4 ? (row & 3) : NB == 2 ? ((row >> 1) & 1) : 0; }
+template <int NB>
+__device__ __forceinline__ uint4 wg_read_sw(const char* tile, int col0, int krow0, int lane) {
+    const int g = lane >> 4;
+    const int row = krow0 + 8 * (g >> 1) + ((lane & 15) >> 2);
+    const char* p0 = tile + row * (NB * 64) + (((col0 >> 5) ^ wg_key<NB>(row)) << 6) + 32 * (g & 1) + 8 * (lane & 3);
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v*)(p0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v*)(p0 + 4 * NB * 64));   // row + 4: same key
+    uint4 r;
+    r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return r;
+}
 template <> struct WgFrag<float> {
     // 4 MFMA 32x32x2 per call: element j of lane-half h is pixel krow0 + 2*j + h
     static __device__ __forceinline__ uint4 read(const char* tile, int pitch, int col0, int krow0, int lane) {
@@ -852,20 +871,24 @@ template <> struct WgFrag<float> {
 template <typename T> struct WgTile { static constexpr int BKP = 64; };   // pixels per K' tile
 template <> struct WgTile<float> { static constexpr int BKP = 32; };
 
-template <typename T, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
+template <typename T, int WM, int WN, bool DMA>
+__global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {   // 2nd = waves per SIMD
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(!DMA || sizeof(T) == 2, "LDS-DMA layout is for the 16-bit types");
     constexpr int BKP = WgTile<T>::BKP;
     constexpr int EPC = 16 / (int)sizeof(T);                 // elements per 16-byte chunk
     constexpr int CY = 64 * WM / EPC, CX = 64 * WN / EPC;    // chunks per tile row
     constexpr int SY = BKP * CY / 256, SX = BKP * CX / 256;  // slots per thread
-    constexpr int PY = 64 * WM * (int)sizeof(T) + 64, PX = 64 * WN * (int)sizeof(T) + 64;   // row pitches
+    constexpr int PY = 64 * WM * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);   // row pitches
+    constexpr int NBY = 2 * WM, NBX = 2 * WN;                 // 64-byte blocks per row (DMA layout)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ty = smem;               // single LDS buffer: the next tile waits in registers
     char* const tx = smem + BKP * PY;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int wave1k = __builtin_amdgcn_readfirstlane(wave) * 1024;      // this wave's first DMA piece (1 KiB each)
     const int ntq = (p.Q + 64 * WN - 1) / (64 * WN);
     // 1-D grid over (split, tile), split-major, dealt to the XCDs in contiguous chunks: the tiles of one split read the
     // same pixel range of x and dy, so they share one L2 instead of pulling those rows into all eight
@@ -878,13 +901,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dybytes, 0x00020000);
 
     // dY slots: dense rows; column fixed per thread
-    const int ychunk = t % CY, yrow = t / CY;
+    const int yrow = t / CY;
+    // DMA: this thread's LDS slot is fixed (piece base + lane * 16); the SOURCE chunk it fetches is the swizzled one
+    const int ychunk = DMA ? ((((t % CY) >> 2) ^ wg_key<NBY>(yrow)) << 2) | ((t % CY) & 3) : t % CY;
     const int yn = n0 + ychunk * EPC;
     const unsigned ycol = yn < p.ldn ? (unsigned)yn * (unsigned)sizeof(T) : kOOB;
     const unsigned yrowbytes = (unsigned)p.ldn * (unsigned)sizeof(T);
     // X slots: fixed tap / channel per thread; the pixel moves by one K' tile per trip.  Its source coordinates
     // (ih, iw) and byte offset are advanced incrementally with adds / selects only (no multiply, no divide).
-    const int xchunk = t % CX, xrow = t / CX;
+    const int xrow = t / CX;
+    const int xchunk = DMA ? ((((t % CX) >> 2) ^ wg_key<NBX>(xrow)) << 2) | ((t % CX) & 3) : t % CX;
     const int q = q0 + xchunk * EPC;
     const int rs = q / p.C, c = q - rs * p.C;
     const int r = rs / p.S, s = rs - r * p.S;
@@ -918,14 +944,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
 #pragma unroll
         for (int i = 0; i < SY; ++i) {
             const int m = k0 + yrow + i * (256 / CY);
-            ry[i] = bload(yr, (m < kend && ycol < kOOB) ? y_off[i] : kOOB);
+            const unsigned voff = (m < kend && ycol < kOOB) ? y_off[i] : kOOB;
+            if (DMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_void*)(ty + (wave1k + i * 4096)), 16, (int)voff, 0, 0, 0);
+            else
+                ry[i] = bload(yr, voff);
             y_off[i] += y_step;
         }
 #pragma unroll
         for (int i = 0; i < SX; ++i) {
             const int m = k0 + xrow + i * (256 / CX);
             const bool ok = xcol_ok && m < kend && (unsigned)x_ih[i] < (unsigned)p.H && (unsigned)x_iw[i] < (unsigned)p.W;
-            rx[i] = bload(xr, ok ? x_off[i] : kOOB);
+            if (DMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(tx + (wave1k + i * 4096)), 16,
+                                                         (int)(ok ? x_off[i] : kOOB), 0, 0, 0);
+            else
+                rx[i] = bload(xr, ok ? x_off[i] : kOOB);
             // advance this slot by one K' tile
             x_iw[i] += d_iw;
             x_ih[i] += d_ih;
@@ -953,6 +987,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
     // one K' tile of register prefetch (a second register set was measured: it costs a wave of occupancy and
     // runs 35 % slower -- three co-resident workgroups per CU hide the load latency better)
     uint4 ry[SY], rx[SX];
+    if (DMA) {
+        // single LDS buffer filled by LDS-DMA (as the forward kernel, mode 3): no staging registers, no ds_write
+        for (int kt = 0; kt < nkt; ++kt) {
+            load_tile(kbeg + kt * BKP, ry, rx);
+            __syncthreads();          // vmcnt(0) + barrier: the tile has landed
+#pragma unroll
+            for (int ks = 0; ks < BKP / 16; ++ks) {
+                uint4 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = wg_read_sw<NBY>(ty, wm * 64 + i * 32, ks * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = wg_read_sw<NBX>(tx, wn * 64 + j * 32, ks * 16, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+            }
+            __syncthreads();          // everybody is done reading before the next fill
+        }
+    } else {
     if (nkt > 0) {
         load_tile(kbeg, ry, rx);
         store_tile(ry, rx);
@@ -975,6 +1029,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
         __syncthreads();
         if (kt + 1 < nkt) store_tile(ry, rx);
         __syncthreads();
+    }
     }
 
     float* out = p.slab + (size_t)split * p.N * p.Q;
@@ -1018,21 +1073,30 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
     }
 }
 
-template <typename T, int WM, int WN>
-static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
-    constexpr int PY = 64 * WM * (int)sizeof(T) + 64, PX = 64 * WN * (int)sizeof(T) + 64;
+template <typename T, int WM, int WN, bool DMA>
+static int launch_wgrad_v(const WgP& p, int splits, hipStream_t st) {
+    constexpr int PY = 64 * WM * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);
     const int lds = WgTile<T>::BKP * (PY + PX);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN, DMA>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     WgP q = p;
     q.tiles = ((p.N + 64 * WM - 1) / (64 * WM)) * ((p.Q + 64 * WN - 1) / (64 * WN));
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN>), dim3((unsigned)(q.tiles * splits)), dim3(256), lds, st, q);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, DMA>), dim3((unsigned)(q.tiles * splits)), dim3(256), lds, st, q);
     MRFP_LAUNCH_CHECK();
     return 0;
+}
+
+// MRFP_WGRAD_DMA=0 keeps register staging for the 16-bit types (A/B measurements); fp32 always stages in registers
+template <typename T, int WM, int WN>
+static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
+    static int dma = -1;
+    if (dma < 0) { const char* e = getenv("MRFP_WGRAD_DMA"); dma = e ? atoi(e) : 1; }
+    if (sizeof(T) == 2 && dma) return launch_wgrad_v<T, WM, WN, sizeof(T) == 2>(p, splits, st);
+    return launch_wgrad_v<T, WM, WN, false>(p, splits, st);
 }
 
 static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen) {
