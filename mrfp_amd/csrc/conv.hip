@@ -508,8 +508,12 @@ static int pick_igemm(const ConvP& p, hipStream_t st) {
 static int g_big = -1;
 static bool use_big_tile(const ConvP& p, int esz) {
     if (g_big < 0) {
-        const char* e = getenv("MRFP_CONV_BIGTILE");    // MRFP_CONV_BIGTILE=0 disables the 256x256 tile (A/B measurements)
-        g_big = e ? atoi(e) : 1;
+        // MRFP_CONV_BIGTILE=1 enables the 256x256 / 8-wave / double-buffered LDS-DMA tile.  It won on long-K layers while
+        // the 4-wave tiles staged through registers (+8..15 %); since those use single-buffer LDS-DMA (4 workgroups per
+        // CU) the 128x128 tile is as fast or faster on every layer of the bench workload (41.2 vs 41.7 ms of
+        // convolutions per step), so it is off by default.
+        const char* e = getenv("MRFP_CONV_BIGTILE");
+        g_big = e ? atoi(e) : 0;
     }
     if (!g_big || esz != 2 || p.N <= 64) return false;
     const int64_t m256 = (p.M + 255) / 256, n256 = (p.N + 255) / 256;
