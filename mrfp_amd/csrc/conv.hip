@@ -543,8 +543,21 @@ static bool use_tile96(const ConvP& p, int esz) {
     const int64_t c128 = ((t128 + 767) / 768) * 128, c96 = ((t96 + 1023) / 1024) * 96;
     return c96 * 10 <= c128 * 9;       // at least 10 % fewer row-rounds
 }
+// 192x128 tile (4 waves x 96x64): 77 FLOP per LDS-fill byte instead of 64 and 0.83 KiB of fragment reads per MFMA instead
+// of 1; for long-K layers with many rounds of tiles
+static int g_t192 = -1;
+static bool use_tile192(const ConvP& p, int esz) {
+    if (g_t192 < 0) {
+        const char* e = getenv("MRFP_CONV_T192");      // =0: A/B measurements (measured +4..5 % on the long-K layers)
+        g_t192 = e ? atoi(e) : 1;
+    }
+    if (!g_t192 || esz != 2 || p.N <= 64 || use_big_tile(p, esz) || use_tile96(p, esz)) return false;
+    const int nkt = (p.kchunks + 7) >> 3;
+    return nkt >= 9 && ((p.M + 191) / 192) * ((p.N + 127) / 128) >= 2048;
+}
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
 static int64_t stats_row_blocks(const ConvP& p, int esz) {
+    if (p.N > 64 && use_tile192(p, esz)) return (int64_t)((p.M + 191) / 192) * 2;      // <2,2,3,2>: 192-row tile, 2 wave rows
     if (p.N <= 64) return (int64_t)((p.M + 255) / 256) * 4;          // <4,1,2,2>: 256-row tile, 4 wave rows
     if (use_big_tile(p, esz)) return (int64_t)((p.M + 255) / 256) * 2;  // <2,4,4,2>: 256-row tile, 2 wave rows
     if (use_tile96(p, esz)) return (int64_t)((p.M + 95) / 96);          // <1,4,3,1>: 96-row tile, 1 wave row
@@ -563,6 +576,7 @@ static int run_igemm(const ConvP& p, hipStream_t st) {
     // (measured and dropped: a two-wave 96x128 variant, 2 x (96x64), 216 registers, fewer LDS reads per MFMA: 5-25 %
     //  slower; a 256x128 8-wave LDS-DMA tile for the N = 128 layers: 753 vs 803 TF/s at 16x384x384x256 -> 128)
     if (use_tile96(p, (int)sizeof(T))) return pick_igemm<T, 1, 4, 3, 1>(p, st);
+    if (use_tile192(p, (int)sizeof(T))) return pick_igemm<T, 2, 2, 3, 2>(p, st);
     return pick_igemm<T, 2, 2, 2, 2>(p, st);
 }
 
