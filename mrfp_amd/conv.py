@@ -86,6 +86,8 @@ def repack_all():
             w = pk.wref() if getattr(pk, "wref", None) is not None else None
             if w is None or pk.bias is not None or not w.requires_grad or w.dtype != torch.float32 or not w.is_contiguous():
                 continue
+            if w.shape[2] * w.shape[3] > 9:           # the brick kernel holds up to 3x3 taps; the 7x7 stem packs lazily
+                continue
             todo.append((key, pk, w))
     if not todo:
         return
@@ -103,7 +105,7 @@ def repack_all():
                 _, Cphys, Nphys = key[0], key[1], key[2]
                 rec[i]["w"], rec[i]["wf"], rec[i]["wd"] = w.data_ptr(), pk.wf.data_ptr(), pk.wd.data_ptr()
                 rec[i]["dims"] = (N, C, R, S, Nphys, Cphys)
-                prefix[i + 1] = prefix[i] + Nphys * R * S * Cphys + C * R * S * Nphys
+                prefix[i + 1] = prefix[i] + ((Nphys + 63) // 64) * ((Cphys + 7) // 8)      # 64 x 8 x R x S bricks
             dev = items[0][2].device
             st = {"sig": sig, "jobs": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
                   "prefix": torch.from_numpy(prefix).to(dev), "total": int(prefix[-1]), "n": len(items)}

@@ -621,38 +621,49 @@ struct PackJob {
     void* wd;
     int N, C, R, S, Npad, Cpad;
 };
+// One workgroup = one (job, 64 output channels n, 8 input channels c) brick: it reads the 64 runs w[n][c0..c0+7][:][:] of
+// 8*R*S contiguous floats (coalesced), keeps the brick in LDS, and writes both packs from there with the channel index
+// that is contiguous in the pack as the fastest thread index: wf[n][r][s][c0..c0+7] (16-byte runs) and
+// wd[c][R-1-r][S-1-s][n0..n0+63] (128-byte runs).  prefix[] counts bricks (plus the pad bricks that zero the padding).
+constexpr int kBrickN = 64, kBrickC = 8, kBrickRSMax = 9;      // filters up to 3x3 (18.7 KB of LDS); larger ones pack per layer
 template <typename T>
-__global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int64_t* __restrict__ prefix, int njobs,
-                                            int64_t total) {
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        int lo = 0, hi = njobs;                 // largest j with prefix[j] <= g
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (prefix[mid] <= g) lo = mid; else hi = mid;
-        }
-        const PackJob jb = jobs[lo];
-        const int64_t i = g - prefix[lo];
-        const int N = jb.N, C = jb.C, R = jb.R, S = jb.S, Npad = jb.Npad, Cpad = jb.Cpad;
-        const int64_t nf = (int64_t)Npad * R * S * Cpad;
-        const float* w = jb.w;
-        if (i < nf) {
-            const int c = (int)(i % Cpad);
-            int64_t rest = i / Cpad;
-            const int s2 = (int)(rest % S); rest /= S;
-            const int r = (int)(rest % R);
-            const int n = (int)(rest / R);
-            const float v = (n < N && c < C) ? w[(((int64_t)n * C + c) * R + r) * S + s2] : 0.f;
-            reinterpret_cast<T*>(jb.wf)[i] = from_f<T>(v);
-        } else {
-            const int64_t k = i - nf;
-            const int n = (int)(k % Npad);
-            int64_t rest = k / Npad;
-            const int s2 = (int)(rest % S); rest /= S;
-            const int r = (int)(rest % R);
-            const int c = (int)(rest / R);
-            const float v = (n < N) ? w[(((int64_t)n * C + c) * R + (R - 1 - r)) * S + (S - 1 - s2)] : 0.f;
-            reinterpret_cast<T*>(jb.wd)[k] = from_f<T>(v);
-        }
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs,
+                                                                    const int64_t* __restrict__ prefix, int njobs, int64_t total) {
+    __shared__ float brick[kBrickN][kBrickC * kBrickRSMax + 1];
+    const int64_t wg = blockIdx.x;
+    int lo = 0, hi = njobs;                 // largest j with prefix[j] <= wg  (uniform: every lane does the same search)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= wg) lo = mid; else hi = mid;
+    }
+    const PackJob jb = jobs[lo];
+    const int N = jb.N, C = jb.C, R = jb.R, S = jb.S, Npad = jb.Npad, Cpad = jb.Cpad, RS = R * S;
+    const int ncb = (Cpad + kBrickC - 1) / kBrickC;
+    const int local = (int)(wg - prefix[lo]);
+    const int n0 = (local / ncb) * kBrickN, c0 = (local % ncb) * kBrickC;
+    const int run = kBrickC * RS;           // floats per n in this brick (contiguous in w when c0 + 8 <= C)
+    const int t = threadIdx.x;
+    for (int e = t; e < kBrickN * run; e += 256) {
+        const int nn = e / run, k = e - nn * run;          // k = cc*RS + rs
+        const int n = n0 + nn, c = c0 + k / RS;
+        brick[nn][k] = (n < N && c < C) ? jb.w[((size_t)n * C + c0) * RS + k] : 0.f;
+    }
+    __syncthreads();
+    T* wf = reinterpret_cast<T*>(jb.wf);
+    T* wd = reinterpret_cast<T*>(jb.wd);
+    // forward pack: wf[n][rs][c]  (c fastest over 8 consecutive threads)
+    for (int e = t; e < kBrickN * run; e += 256) {
+        const int cc = e % kBrickC, rest = e / kBrickC;
+        const int rs = rest % RS, nn = rest / RS;
+        const int n = n0 + nn, c = c0 + cc;
+        if (n < Npad && c < Cpad) wf[((size_t)n * RS + rs) * Cpad + c] = from_f<T>(brick[nn][cc * RS + rs]);
+    }
+    // dgrad pack: wd[c][flipped rs][n]  (n fastest over 64 consecutive threads); only real input channels have rows
+    for (int e = t; e < kBrickN * run; e += 256) {
+        const int nn = e % kBrickN, rest = e / kBrickN;
+        const int rs = rest % RS, cc = rest / RS;
+        const int n = n0 + nn, c = c0 + cc;
+        if (n < Npad && c < C) wd[((size_t)c * RS + (RS - 1 - rs)) * Npad + n] = from_f<T>(brick[nn][cc * RS + rs]);
     }
 }
 
@@ -750,9 +761,9 @@ int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, i
 }
 
 int mrfp_pack_weights_batched(const void* jobs, const int64_t* prefix, int64_t njobs, int64_t total, int dtype, void* stream) {
-    MRFP_CHECK(jobs && prefix && njobs > 0 && total > 0, "pack_weights_batched: bad arguments");
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
+    MRFP_CHECK(jobs && prefix && njobs > 0 && total > 0, "pack_weights_batched: bad arguments");   /* jobs with R*S > 9 are the caller's error */
+    const int64_t blocks = total;           // one workgroup per brick
+    MRFP_CHECK(blocks < (1LL << 31), "pack_weights_batched: too many bricks");
     const mrfp::PackJob* jb = (const mrfp::PackJob*)jobs;
     if (dtype == MRFP_F32)
         hipLaunchKernelGGL((pack_weights_batched_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jb, prefix, (int)njobs, total);
