@@ -551,7 +551,9 @@ static bool use_tile192(const ConvP& p, int esz) {
         const char* e = getenv("MRFP_CONV_T192");      // =0: A/B measurements (measured +4..5 % on the long-K layers)
         g_t192 = e ? atoi(e) : 1;
     }
-    if (!g_t192 || esz != 2 || p.N <= 64 || use_big_tile(p, esz) || use_tile96(p, esz)) return false;
+    if (!g_t192 || esz != 2 || p.N <= 64 || use_big_tile(p, esz)) return false;
+    if (g_t192 == 2) return true;        // A/B measurements: 192-row tile wherever it is legal
+    if (use_tile96(p, esz)) return false;
     const int nkt = (p.kchunks + 7) >> 3;
     return nkt >= 9 && ((p.M + 191) / 192) * ((p.N + 127) / 128) >= 2048;
 }
@@ -575,8 +577,8 @@ static int run_igemm(const ConvP& p, hipStream_t st) {
     if (use_big_tile(p, (int)sizeof(T))) return pick_igemm<T, 2, 4, 4, 2>(p, st);
     // (measured and dropped: a two-wave 96x128 variant, 2 x (96x64), 216 registers, fewer LDS reads per MFMA: 5-25 %
     //  slower; a 256x128 8-wave LDS-DMA tile for the N = 128 layers: 753 vs 803 TF/s at 16x384x384x256 -> 128)
-    if (use_tile96(p, (int)sizeof(T))) return pick_igemm<T, 1, 4, 3, 1>(p, st);
     if (use_tile192(p, (int)sizeof(T))) return pick_igemm<T, 2, 2, 3, 2>(p, st);
+    if (use_tile96(p, (int)sizeof(T))) return pick_igemm<T, 1, 4, 3, 1>(p, st);
     return pick_igemm<T, 2, 2, 2, 2>(p, st);
 }
 
