@@ -53,6 +53,9 @@ cfg.MODEL.ACT_DTYPE = torch.float32
 cfg.MODEL.CONV_BACKEND = "hip"
 # training: fuse final bilinear upsample + cross entropy (the full-resolution logits are never written)
 cfg.MODEL.FUSE_UPSAMPLE_CE = True
+# MRFP+ head: evaluate final2(Upsample(dec1) + OCout_dec) as Upsample(final2(dec1)) + final2(OCout_dec) (a 1x1 conv
+# commutes with bilinear interpolation): the 2x upsample runs on the class scores, not on 256 channels
+cfg.MODEL.COMMUTE_O2 = __import__("os").environ.get("MRFP_COMMUTE_O2", "1") != "0"
 # directory searched for ImageNet checkpoints when pretrained=True (no network access here)
 cfg.MODEL.PRETRAINED_DIR = None
 

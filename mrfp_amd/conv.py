@@ -193,6 +193,83 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+class _SharedConv1x1Pair(torch.autograd.Function):
+    """(conv1x1(x1, W), conv1x1(x2, W) + b): ONE weight applied to two activations of different resolution.  Used by the
+    MRFP+ head, where final2(Upsample(dec1) + OCout_dec) is evaluated as Upsample(final2(dec1)) + final2(OCout_dec) (a 1x1
+    convolution commutes with bilinear interpolation), so the 2x upsample runs on the class scores instead of on 256
+    channels.  One Function for both uses keeps the shared weight gradient a single sink write + a single ready
+    notification (the gradient-arena protocol of _Conv2d assumes one use per weight)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, Nphys):
+        N, C, R, S = weight.shape
+        if R != 1 or S != 1 or x1.shape[1] != C or x2.shape[1] != C:
+            raise _lib.MrfpHipError("shared conv pair: 1x1 weight and unpadded inputs expected")
+        pk = get_pack(weight, bias, x1.dtype, C, Nphys)
+        ys = []
+        for x, b in ((x1, None), (x2, pk.bias)):
+            B, _, H, W = x.shape
+            y = empty_cl(B, Nphys, H, W, x.dtype, x.device)
+            call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(b), ptr(y), dt(x), B, H, W, C, Nphys, Nphys, 1, 1, H, W, 1, 0, 0, 1, 1,
+                 None, None, stream())
+            ys.append(y)
+        ctx.save_for_backward(x1, x2, weight, bias)
+        ctx.Nphys = Nphys
+        ctx.set_materialize_grads(False)
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x1, x2, weight, bias = ctx.saved_tensors
+        N, C, _, _ = weight.shape
+        Nphys = ctx.Nphys
+        pk = get_pack(weight, bias, x1.dtype, C, Nphys)
+        dxs, dws = [], []
+        db = None
+        for x, dy, need_dx in ((x1, dy1, ctx.needs_input_grad[0]), (x2, dy2, ctx.needs_input_grad[1])):
+            if dy is None:
+                dxs.append(None)
+                continue
+            dy = _chk(dy, "dy")
+            B, _, H, W = x.shape
+            dx = None
+            if need_dx:
+                dx = empty_cl(B, C, H, W, x.dtype, x.device)
+                call("mrfp_conv_fwd", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, H, W, Nphys, C, C, 1, 1, H, W, 1, 0, 0, 1, 1,
+                     None, None, stream())
+            dxs.append(dx)
+            if ctx.needs_input_grad[2]:
+                M = B * H * W
+                ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, C)), dtype=torch.uint8, device=x.device)
+                dw = torch.empty((N, C, 1, 1), dtype=torch.float32, device=x.device)
+                call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), dt(x), B, H, W, C, C, N, Nphys, 1, 1, H, W, 1, 0, 0, 1,
+                     stream())
+                dws.append(dw)
+        if bias is not None and ctx.needs_input_grad[3] and dy2 is not None:
+            from .ops import _stats_fwd
+            d2 = _chk(dy2, "dy")
+            B2, _, H2, W2 = d2.shape
+            nslab, sws = _stats_fwd(d2, None)
+            out = torch.empty(4 * Nphys, dtype=torch.float32, device=d2.device)
+            call("mrfp_bn_finalize", ptr(sws), B2, nslab, B2 * H2 * W2, Nphys, None, None, 0.0, 0.0, None, None,
+                 ptr(out[:Nphys]), ptr(out[Nphys:2 * Nphys]), ptr(out[2 * Nphys:3 * Nphys]), ptr(out[3 * Nphys:]), stream())
+            db = (out[:N] * float(B2 * H2 * W2)).to(bias.dtype)       # column mean * count = column sum
+        dw = None
+        if dws:
+            total = dws[0] if len(dws) == 1 else dws[0].add_(dws[1])
+            sink = grad_sink(weight)
+            if sink is not None:
+                sink.copy_(total)
+                notify_grad(weight)
+            else:
+                dw = total.to(weight.dtype)
+        return dxs[0], dxs[1], dw, db, None
+
+
+def shared_conv1x1_pair(x1, x2, weight, bias, phys_out):
+    return _SharedConv1x1Pair.apply(_chk(x1), _chk(x2), weight, bias, int(phys_out))
+
+
 def pad_input_channels(x: torch.Tensor, dtype) -> torch.Tensor:
     """Network input NCHW fp32 -> NHWC `dtype` with the channel count padded to a 16-byte chunk."""
     if not x.is_cuda:

@@ -229,6 +229,24 @@ class _DeepLabBase(nn.Module):
             return self._loss(main_out, gts)
         return main_out.float()
 
+    def _head_o2(self, dec1, oc_dec, size, gts, training):
+        """final2(Upsample(dec1) + OCout_dec) (reference deepv3.py:355-361) evaluated as
+        Upsample(final2_nobias(dec1)) + final2(OCout_dec): the 1x1 convolution commutes with the bilinear
+        interpolation, so the 2x upsample and its backward run on the 19 (padded 32) class-score planes instead of on 256
+        channels.  Same arithmetic up to fp32 summation order (inside the 1e-3 parity bound, tests/test_model_gpu.py)."""
+        from . import conv
+        f2 = self.final2[0]
+        nc = f2.out_channels
+        pitch = (nc + 31) // 32 * 32
+        p_low, p_half = conv.shared_conv1x1_pair(dec1, oc_dec, f2.weight, f2.bias, pitch)
+        dec2 = ops.upsample_bilinear(p_low, (oc_dec.shape[2], oc_dec.shape[3]), addend=p_half)
+        if training and cfg.MODEL.FUSE_UPSAMPLE_CE and self._plain_ce():
+            return ops.upsample_cross_entropy(dec2, gts, size, nc, self.criterion.ignore_index)
+        main_out = ops.upsample_bilinear(dec2, size, channels=nc)
+        if training:
+            return self._loss(main_out, gts)
+        return main_out.float()
+
     def _loss(self, main_out, gts):
         if self._plain_ce():
             return ops.cross_entropy(main_out, gts, self.criterion.ignore_index)
@@ -322,8 +340,10 @@ class MRFPPlus(_DeepLabBase):
         dec0_up = self.bot_aspp(t)
         dec0_up = Upsample(dec0_up, low_level.shape[2:])
         dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))
-        if o2:                                         # "+" of MRFP+: deepv3.py:355-357, one fused pass
-            dec1 = ops.upsample_bilinear(dec1, (int(h / 2), int(w / 2)), addend=OCout_dec)
+        if o2:                                         # "+" of MRFP+: deepv3.py:355-357
+            if cfg.MODEL.CONV_BACKEND == "hip" and cfg.MODEL.COMMUTE_O2:
+                return self._head_o2(dec1, OCout_dec, (h, w), gts, training)
+            dec1 = ops.upsample_bilinear(dec1, (int(h / 2), int(w / 2)), addend=OCout_dec)   # one fused pass
         return self._head(dec1, (h, w), gts, training)
 
 
