@@ -472,15 +472,8 @@ static int launch_igemm_nb(const ConvP& p, hipStream_t st) {
     return 0;
 }
 
-static int g_nbuf = 0;   // 0 = unset; 1 / 2 forced through MRFP_CONV_NBUF (for A/B measurements); default 1
-
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int TM, int TN>
 static int launch_igemm(const ConvP& p, hipStream_t st) {
-    if (g_nbuf == 0) {
-        const char* e = getenv("MRFP_CONV_NBUF");
-        g_nbuf = e ? atoi(e) : 1;
-        if (g_nbuf != 2) g_nbuf = 1;   // default (measured on MI355X): single buffer, 3 workgroups per CU
-    }
     // MRFP_CONV_DMA (A/B measurements): 0 = register staging everywhere; 1 = LDS-DMA (two buffers) for the 8-wave tile
     // only; 2 = LDS-DMA with two buffers everywhere; 3 (default) = LDS-DMA everywhere, ONE buffer for the 4-wave tiles
     // (no staging registers, no ds_write: 112 / 90 registers -> 4-5 workgroups per CU hide each other's fill latency;
@@ -494,8 +487,7 @@ static int launch_igemm(const ConvP& p, hipStream_t st) {
     if ((dma == 1 && TM * TN >= 8) || dma == 2) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
     if ((dma == 3 && TM * TN < 8) || dma == 4) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, true>(p, st);
     if (dma == 3) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
-    if (TM * TN >= 8 || g_nbuf == 1) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, false>(p, st);
-    return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, false>(p, st);
+    return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, false>(p, st);       // register staging, one LDS buffer
 }
 
 template <typename T, int WM, int WN, int TM, int TN>
@@ -574,10 +566,14 @@ static int run_igemm(const ConvP& p, hipStream_t st) {
     // (998 vs 913 TF/s at 16x192x192x256->256), but -25 % with ~1 round (M = 36 864), -20 % on short-K 1x1
     // layers (fill / drain dominate) and on N that wastes most of the second 256-column tile; a 256x128
     // 4-wave variant (254 VGPRs) lost 25 % everywhere and was dropped.
-    if (use_big_tile(p, (int)sizeof(T))) return pick_igemm<T, 2, 4, 4, 2>(p, st);
+    if constexpr (sizeof(T) == 2) {      // 16-bit types only (no fp32 instantiation of these two tiles)
+        if (use_big_tile(p, (int)sizeof(T))) return pick_igemm<T, 2, 4, 4, 2>(p, st);
+    }
     // (measured and dropped: a two-wave 96x128 variant, 2 x (96x64), 216 registers, fewer LDS reads per MFMA: 5-25 %
     //  slower; a 256x128 8-wave LDS-DMA tile for the N = 128 layers: 753 vs 803 TF/s at 16x384x384x256 -> 128)
-    if (use_tile192(p, (int)sizeof(T))) return pick_igemm<T, 2, 2, 3, 2>(p, st);
+    if constexpr (sizeof(T) == 2) {
+        if (use_tile192(p, (int)sizeof(T))) return pick_igemm<T, 2, 2, 3, 2>(p, st);
+    }
     if (use_tile96(p, (int)sizeof(T))) return pick_igemm<T, 1, 4, 3, 1>(p, st);
     return pick_igemm<T, 2, 2, 2, 2>(p, st);
 }
