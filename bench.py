@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--backend", default="hip", choices=["hip", "miopen"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay zero_grad + forward + backward as a hipGraph (single GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--dump-convs", default=None, help="write per-launch conv shapes/timings (JSON) here")
     return ap.parse_args()
@@ -145,6 +146,8 @@ def main():
     model = model.to(dev).train()
     model.rng = deepv3.InjectedRandom((True, True, True), None, reinit=True)   # all perturbations on, HRFP re-drawn
     trainer = Trainer(model)
+    if args.graph:
+        trainer.enable_graph()
     width = args.width or args.size
     x, y = synth.synth_batch(args.batch, args.size, width, seed=1 + rank)
     x, y = x.to(dev), y.to(dev)
@@ -198,6 +201,15 @@ def main():
         print(json.dumps(out))
 
 
+def _eager_step(trainer, x, y):
+    """one eager (non-graph) step: the per-launch timing below spies on the Python-side conv calls"""
+    was, trainer.graph = trainer.graph, False
+    try:
+        return trainer.step(x, y)
+    finally:
+        trainer.graph = was
+
+
 def conv_roofline(model, trainer, x, y, args):
     """Times every MFMA convolution launch (fwd / dgrad / wgrad) of one train step with hipEvents recorded on
     the launch stream, and divides their algorithmic FLOPs by the summed durations."""
@@ -227,7 +239,7 @@ def conv_roofline(model, trainer, x, y, args):
         return orig(name, *a)
     conv_mod.call = spy
     try:
-        trainer.step(x, y)
+        _eager_step(trainer, x, y)
         torch.cuda.synchronize()
     finally:
         conv_mod.call = orig

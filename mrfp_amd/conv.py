@@ -61,13 +61,17 @@ def get_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, Cphys: i
         pk.wf = torch.empty(Nphys * R * S * Cphys, dtype=dtype, device=dev)
         pk.wd = torch.empty(C * R * S * Nphys, dtype=dtype, device=dev)
         pk.bias = None
+        pk.version = None
         pk.wref = weakref.ref(weight)
     call("mrfp_pack_weight", ptr(w32), ptr(pk.wf), ptr(pk.wd), _lib._DT[dtype], N, C, R, S, Nphys, Cphys, stream())
     if bias is not None:
-        b32 = torch.zeros(Nphys, dtype=torch.float32, device=dev)
-        b32[:N].copy_(bias.detach())
-        pk.bias = b32
-    pk.version = ver
+        if pk.bias is None:                      # allocated once (pad entries stay zero), refreshed in place
+            pk.bias = torch.zeros(Nphys, dtype=torch.float32, device=dev)
+        pk.bias[:N].copy_(bias.detach())
+    # under hipGraph capture (harness.Trainer.enable_graph) the pack kernel is only recorded, not run: the cached pack
+    # must stay "stale" for eager code, and the recorded kernel re-packs on every replay
+    if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        pk.version = ver
     per_w[key] = pk
     return pk
 

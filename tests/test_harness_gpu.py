@@ -145,3 +145,32 @@ def test_eval_harness_hist_miou_and_checkpoint_roundtrip(tmp_path):
         model.eval()
         l0 = model(x.to(DEV), training=False)
     assert torch.equal(l0, l1)
+
+
+def test_graph_mode_matches_eager():
+    """Trainer.enable_graph(): zero_grad + forward + backward captured into a hipGraph per toggle combination and
+    replayed; with fixed noise and no HRFP re-draw the captured kernels are the eager ones, so losses and parameters
+    after 5 steps (two toggle combinations, each seen before and after its capture) must be bitwise identical."""
+    from mrfp_amd.deepv3 import InjectedRandom
+    from mrfp_amd.harness import Trainer
+    toggles = [(True, True, True), (False, True, False), (True, True, True), (False, True, False), (True, True, True)]
+    x, y = synth.synth_batch(2, 128, 128, seed=3)
+    x, y = x.to(DEV), y.to(DEV)
+    noise = {k: v.to(DEV) for k, v in synth.synth_noise(2, seed=4).items()}
+    out = []
+    for graph in (False, True):
+        model, _ = _model()
+        model.train()
+        tr = Trainer(model, lr=1e-3)
+        if graph:
+            tr.enable_graph()
+        losses = []
+        for i in range(5):
+            model.rng = InjectedRandom(toggles[i], noise)
+            losses.append(float(tr.step(x, y)))
+        sd = model.state_dict()
+        out.append((losses, sd["final2.0.weight"].clone(), sd["layer1.0.conv1.weight"].clone(),
+                    int(sd["layer1.0.bn1.num_batches_tracked"]), sd["layer1.0.bn1.running_mean"].clone()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3] == 5 and torch.equal(out[0][4], out[1][4])
