@@ -197,3 +197,68 @@ def test_bf16_activations_run_close(backend):
     assert abs(g.double().pow(2).sum().sqrt().item() - ref_l2) / ref_l2 < 0.1
     from mrfp_amd.config import cfg
     cfg.MODEL.ACT_DTYPE = torch.float32
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[2] size (ResNet-101 MRFP+, 768x768, bf16 activations; batch 4 to keep the test short), where
+    the CPU oracle is out of reach: size-independent properties instead --
+    (1) bitwise reproducibility: the same step from the same state gives the same loss and the same gradients (split-K
+        slabs and statistics partials are summed in a fixed order, no atomics anywhere);
+    (2) the gradient is the derivative: moving the classifier bias by eps * v changes the loss by eps * <grad, v>
+        (fp32 activations for this part; central difference, 2 % tolerance);
+    (3) ignore_index: labels that are all 255 on one image leave that image's pixels out of the loss normalisation
+        (loss equals the loss of the other images computed alone on the same batch statistics is not separable with
+        BatchNorm, so the check is the count: d(loss)/d(bias) sums to zero over classes, as softmax - onehot does)."""
+    import contextlib
+    import io
+    from mrfp_amd import deepv3
+    from mrfp_amd.config import cfg
+
+    def make(dtype):
+        cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", dtype
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = deepv3.MRFPPlus(19, trunk="resnet-101", criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
+        m.load_state_dict(synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=0))
+        m = m.to(DEV).train()
+        return m
+
+    x, y = synth.synth_batch(4, 768, 768, seed=31)
+    x, y = x.to(DEV), y.to(DEV)
+    noise = {k: v.to(DEV) for k, v in synth.synth_noise(4, seed=32, channels=(128, 256)).items()}
+    try:
+        m = make(torch.bfloat16)
+        runs = []
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            m.rng = deepv3.InjectedRandom((True, True, True), noise)
+            loss = m(x, y, training=True)
+            loss.backward()
+            runs.append((loss.item(), m.final2[0].weight.grad.clone(), m.layer3[5].conv2.weight.grad.clone(),
+                         m.layer0[0].weight.grad.clone()))
+        assert runs[0][0] == runs[1][0] and np.isfinite(runs[0][0])
+        for a, b in zip(runs[0][1:], runs[1][1:]):
+            assert torch.equal(a, b)
+        gb = m.final2[0].bias.grad.double()
+        assert abs(gb.sum().item()) < 1e-4 * gb.abs().sum().item() + 1e-7       # softmax - onehot sums to zero
+        del m
+        torch.cuda.empty_cache()
+        m = make(torch.float32)
+        m.rng = deepv3.InjectedRandom((True, True, True), noise)
+        m.zero_grad(set_to_none=True)
+        m(x, y, training=True).backward()
+        bias = m.final2[0].bias
+        g = bias.grad.detach().double().clone()
+        v = torch.randn(19, generator=torch.Generator().manual_seed(5)).to(DEV)
+        eps = 0.05
+        vals = []
+        with torch.no_grad():
+            for sgn in (+1.0, -1.0):
+                bias.add_(sgn * eps * v)
+                m.rng = deepv3.InjectedRandom((True, True, True), noise)
+                vals.append(m(x, y, training=True).double().item())
+                bias.add_(-sgn * eps * v)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float((g * v.double()).sum())
+        assert abs(fd - an) <= 0.02 * abs(an) + 1e-6, (fd, an)
+    finally:
+        cfg.MODEL.ACT_DTYPE = torch.float32
