@@ -5,14 +5,16 @@
 //              "source stride" for strided convolutions (a tap exists only where the position
 //              divides the stride)
 //
-// Tiling (one workgroup = WM x WN waves, every wave owns a 64x64 output tile = 2x2 MFMA 32x32
-// accumulators): the K dimension is walked in 128-BYTE steps (64 bf16 / 32 fp32 = 8 chunks of
-// 16 bytes).  A chunk never straddles an (r,s) tap because the channel count is a multiple of
-// the chunk, so every 16-byte global load is either a contiguous run of input channels of one
-// pixel or zero (padding) -- im2col happens in the address computation, the matrix is never
-// materialised.  Tiles are staged global -> registers -> LDS (double buffered: the loads of tile
-// k+1 are in flight while tile k is multiplied), LDS rows are 128 B with the 16-byte slot XOR-
-// swizzled by (row>>1)&7 so that the ds_read_b128 fragment reads are bank-conflict free.
+// Tiling (one workgroup = WM x WN waves, every wave owns TM x TN MFMA 32x32 accumulators: 128x128, 192x128, 96x128 or
+// 256x64 outputs per 4-wave workgroup, chosen per launch by run_igemm): the K dimension is walked in 128-BYTE steps
+// (64 bf16 / 32 fp32 = 8 chunks of 16 bytes).  A chunk never straddles an (r,s) tap because the channel count is a
+// multiple of the chunk, so every 16-byte global load is either a contiguous run of input channels of one pixel or zero
+// (padding) -- im2col happens in the address computation, the matrix is never materialised.  Staging (launch_igemm):
+// by default LDS-DMA (buffer_load ... lds) straight into ONE LDS buffer per workgroup -- no staging registers, no
+// ds_write; the 3-5 co-resident workgroups of a CU hide each other's fill latency -- with the register-staged single
+// buffer and the double-buffered LDS-DMA variants kept behind MRFP_CONV_DMA.  LDS rows are 128 B with the 16-byte slot
+// XOR-swizzled by (row>>1)&7 (applied on the SOURCE side for LDS-DMA) so that the ds_read_b128 fragment reads are
+// bank-conflict free.
 //
 //   bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate)       -- bench dtype
 //   fp32: v_mfma_f32_32x32x2_f32   (exact fp32 FMA chains)  -- parity dtype
@@ -97,7 +99,8 @@ __device__ __forceinline__ uint4 bload(const __amdgpu_buffer_rsrc_t& r, unsigned
 // global-load latency behind -- used where the problem has enough 256-row tiles to fill the chip).
 // DMA: tiles go global -> LDS directly (buffer_load ... lds, no staging registers, no ds_write traffic); the LDS
 //      image of one wave-instruction is lane-linear (base + lane*16), so the XOR swizzle is applied to the SOURCE
-//      chunk each lane fetches; needs NBUF == 2 (the DMA of tile k+1 lands while tile k is multiplied).
+//      chunk each lane fetches.  NBUF == 2: the DMA of tile k+1 lands while tile k is multiplied; NBUF == 1: fill, barrier,
+//      multiply, barrier.
 // element access into a 16-byte chunk with COMPILE-TIME indices (keeps the chunk in registers)
 template <typename T> __device__ __forceinline__ T chunk_get(const uint4& v, int u);
 template <> __device__ __forceinline__ float chunk_get<float>(const uint4& v, int u) {
