@@ -125,6 +125,11 @@ int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void
                     const float* P, const float* Q, const float* R,
                     const float* fA, const float* fS, int coef_per_image, void* stream);
 
+/* dst[p][c0_dst + c] = src[p][c0_src + c], c < C, over npix pixels of NHWC tensors with channel pitches ld_src / ld_dst:
+ * torch.cat((...), 1) of reference deepv3.py:125, 353 (one call per input) and its backward (one call per slice). */
+int mrfp_copy_channels(const void* src, void* dst, int dtype, int64_t npix, int64_t C, int64_t ld_src, int64_t c0_src,
+                       int64_t ld_dst, int64_t c0_dst, void* stream);
+
 /* y = a + b, elementwise over n elements (torch.add of reference deepv3.py:330, 357). */
 int mrfp_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
 

@@ -244,6 +244,56 @@ __global__ __launch_bounds__(kThreads) void add_kernel(const T* __restrict__ a, 
     }
 }
 
+// dst[p][c0d + c] = src[p][c0s + c] for c < C over npix pixels (row pitches lds / ldd elements): one block of channels
+// of an NHWC tensor copied into / out of a wider one -- torch.cat(dim=1) and its backward without the detour through a
+// dense temporary.  16-byte chunks; 4 pixels in flight per thread.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void copy_channels_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t npix,
+                                                                  int C, int lds, int c0s, int ldd, int c0d) {
+    const int cpr = C / VEC;                                   // chunks per pixel
+    const int64_t total = npix * cpr;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < total; i0 += 4 * stride) {
+        VecT<T, VEC> r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = min(i0 + u * stride, total - 1);
+            const int64_t pix = i / cpr;
+            const int ch = (int)(i - pix * cpr);
+            r[u] = load_raw<T, VEC>(src + pix * lds + c0s + ch * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < total) {
+                const int64_t pix = i / cpr;
+                const int ch = (int)(i - pix * cpr);
+                *reinterpret_cast<VecT<T, VEC>*>(dst + pix * ldd + c0d + ch * VEC) = r[u];
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_copy_channels(const void* src, void* dst, int64_t npix, int64_t C, int64_t lds, int64_t c0s, int64_t ldd,
+                                int64_t c0d, hipStream_t st) {
+    const int full = FullVec<T>::value;
+    const bool vec_ok = C % full == 0 && lds % full == 0 && ldd % full == 0 && c0s % full == 0 && c0d % full == 0 &&
+                        aligned16(src) && aligned16(dst);
+    const int64_t total = npix * (vec_ok ? C / full : C);
+    int64_t blocks = (total + 4 * kThreads - 1) / (4 * kThreads);
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    if (vec_ok)
+        hipLaunchKernelGGL((copy_channels_kernel<T, FullVec<T>::value>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T*)src, (T*)dst, npix, (int)C, (int)lds, (int)c0s, (int)ldd, (int)c0d);
+    else
+        hipLaunchKernelGGL((copy_channels_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, (const T*)src, (T*)dst,
+                           npix, (int)C, (int)lds, (int)c0s, (int)ldd, (int)c0d);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 static int launch_affine_fwd(const void* x, const void* res, void* y, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
                              int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW, const float* A,
@@ -356,6 +406,17 @@ int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void
     if (dtype == MRFP_BF16) return launch_affine_bwd<bf16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
     if (dtype == MRFP_F16) return launch_affine_bwd<f16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
     MRFP_CHECK(false, "affine_bwd: unknown dtype %d", dtype);
+}
+
+int mrfp_copy_channels(const void* src, void* dst, int dtype, int64_t npix, int64_t C, int64_t ld_src, int64_t c0_src,
+                       int64_t ld_dst, int64_t c0_dst, void* stream) {
+    MRFP_CHECK(src && dst && npix > 0 && C > 0 && c0_src >= 0 && c0_dst >= 0 && c0_src + C <= ld_src && c0_dst + C <= ld_dst,
+               "copy_channels: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return launch_copy_channels<float>(src, dst, npix, C, ld_src, c0_src, ld_dst, c0_dst, st);
+    if (dtype == MRFP_BF16) return launch_copy_channels<bf16>(src, dst, npix, C, ld_src, c0_src, ld_dst, c0_dst, st);
+    if (dtype == MRFP_F16) return launch_copy_channels<f16>(src, dst, npix, C, ld_src, c0_src, ld_dst, c0_dst, st);
+    MRFP_CHECK(false, "copy_channels: unknown dtype %d", dtype);
 }
 
 int mrfp_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream) {

@@ -681,10 +681,46 @@ def conv2d(x, weight, bias, stride, padding, dilation, phys_out=None):
     return torch.nn.functional.conv2d(x, w.contiguous(memory_format=CL), b, stride, padding, dilation)
 
 
+class _ConcatChannels(torch.autograd.Function):
+    """torch.cat(dim=1) of NHWC activations (reference deepv3.py:125, 353): one strided channel-block copy per input
+    straight into the wide buffer, and one per slice on the way back."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ts = [_chk(t) for t in tensors]
+        B, _, H, W = ts[0].shape
+        Cs = [int(t.shape[1]) for t in ts]
+        Ct = sum(Cs)
+        y = empty_cl(B, Ct, H, W, ts[0].dtype, ts[0].device)
+        c0 = 0
+        for t, C in zip(ts, Cs):
+            if tuple(t.shape) != (B, C, H, W) or t.dtype != y.dtype:
+                raise _lib.MrfpHipError("concat_channels: shape / dtype mismatch")
+            call("mrfp_copy_channels", ptr(t), ptr(y), dt(t), B * H * W, C, C, 0, Ct, c0, stream())
+            c0 += C
+        ctx.Cs = Cs
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        B, Ct, H, W = dy.shape
+        out, c0 = [], 0
+        for i, C in enumerate(ctx.Cs):
+            if ctx.needs_input_grad[i]:
+                g = empty_cl(B, C, H, W, dy.dtype, dy.device)
+                call("mrfp_copy_channels", ptr(dy), ptr(g), dt(dy), B * H * W, C, Ct, c0, C, 0, stream())
+                out.append(g)
+            else:
+                out.append(None)
+            c0 += C
+        return tuple(out)
+
+
 def concat_channels(tensors):
-    """torch.cat(dim=1) of NHWC activations (reference deepv3.py:125, 353).  A strided copy: pure
-    data movement by the allocator-side runtime, no arithmetic."""
-    return torch.cat([_chk(t) for t in tensors], 1).contiguous(memory_format=CL)
+    """torch.cat(dim=1) of NHWC activations (reference deepv3.py:125, 353): pure data movement, done by
+    mrfp_copy_channels (a strided channel-block copy) in both directions."""
+    return _ConcatChannels.apply(*tensors)
 
 
 # ------------------------------------------------------------------------------------------

@@ -313,3 +313,21 @@ def test_fused_upsample_cross_entropy(dtype, case):
     assert abs(ld.item() - lc.item()) / abs(lc.item()) < (1e-5 if dtype == torch.float32 else 2e-3)
     assert relerr(Pd.grad[:, :C], xc.grad) < (2e-5 if dtype == torch.float32 else 1.5e-2)
     assert float(Pd.grad[:, C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("chans", [(48, 256), (256, 256, 256, 256, 256), (19, 8), (64,)])
+def test_concat_channels(dtype, chans):
+    """torch.cat(dim=1) of NHWC activations and its backward: strided channel-block copies (bit-exact data movement)."""
+    o = ops()
+    xs = [rnd(2, c, 9, 7, seed=30 + i) for i, c in enumerate(chans)]
+    xd = [x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in xs]
+    y = o.concat_channels(xd)
+    ref = torch.cat([x.to(DEV, dtype) for x in xs], 1)
+    assert torch.equal(y, ref) and y.is_contiguous(memory_format=torch.channels_last)
+    gy = rnd(*ref.shape, seed=40).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    c0 = 0
+    for x, c in zip(xd, chans):
+        assert torch.equal(x.grad, gy[:, c0:c0 + c])
+        c0 += c
