@@ -203,11 +203,14 @@ def main():
 
 def _eager_step(trainer, x, y):
     """one eager (non-graph) step: the per-launch timing below spies on the Python-side conv calls"""
+    import mrfp_amd.conv as conv_mod
     was, trainer.graph = trainer.graph, False
+    side, conv_mod.USE_WGRAD_STREAM[0] = conv_mod.USE_WGRAD_STREAM[0], False      # every conv on the timed stream
     try:
         return trainer.step(x, y)
     finally:
         trainer.graph = was
+        conv_mod.USE_WGRAD_STREAM[0] = side
 
 
 def conv_roofline(model, trainer, x, y, args):

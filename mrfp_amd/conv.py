@@ -123,6 +123,42 @@ def _out_size(H, R, stride, pad, dil):
     return (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
 
 
+# ---- second stream for the weight gradients ---------------------------------------------------------------------
+USE_WGRAD_STREAM = [_os.environ.get("MRFP_WGRAD_STREAM", "1") != "0"]
+_WGRAD_STREAMS = {}
+_WGRAD_PENDING = [False]
+
+
+def wgrad_stream(device):
+    """The side stream weight gradients are computed on (None when disabled or while a hipGraph is being captured)."""
+    if not USE_WGRAD_STREAM[0] or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _WGRAD_STREAMS.get(key)
+    if st is None:
+        st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+_JOIN_QUEUED = [False]
+
+
+def _join_at_end_of_backward():
+    _JOIN_QUEUED[0] = False
+    join_wgrad_stream()
+
+
+def join_wgrad_stream(stream=None):
+    """Makes `stream` (default: the current one) wait for every weight gradient issued so far."""
+    if not _WGRAD_PENDING[0]:
+        return
+    tgt = stream if stream is not None else torch.cuda.current_stream()
+    for st in _WGRAD_STREAMS.values():
+        tgt.wait_stream(st)
+    if stream is None:
+        _WGRAD_PENDING[0] = False
+
+
 class _Conv2d(torch.autograd.Function):
     """want_skip: also return an alias of x for a skip connection; the gradient arriving on that alias is added by
     the dgrad kernel's epilogue (no separate accumulation pass over the activation)."""
@@ -177,16 +213,37 @@ class _Conv2d(torch.autograd.Function):
                  1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), None, stream())
         if ctx.needs_input_grad[1]:
             M, Q = B * Ho * Wo, R * S * Cphys
-            ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
             sink = grad_sink(weight)      # the parameter's slot in the flat gradient arena, when the harness owns it
-            dw = sink if sink is not None else torch.empty((N, C, R, S), dtype=torch.float32, device=x.device)
-            call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), dt(x), B, H, W, Cphys, C, N, Nphys, R, S, Ho, Wo,
-                 stride, pad_h, pad_w, dil, stream())
-            if sink is not None:
+            side = wgrad_stream(x.device) if sink is not None else None
+            if side is not None:
+                # The weight gradient feeds nothing but the optimizer: it runs on a second HIP stream, concurrently with
+                # the dgrad chain of the main stream (its workgroups fill the tails / small-kernel gaps of that chain).
+                # Ordering: side waits for dy (an event on the main stream); the consumers of the arena (optimizer step,
+                # gradient all-reduce) wait for the side stream (harness.Trainer / GradSync, join_wgrad_stream()).
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
+                    call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(sink), ptr(ws), dt(x), B, H, W, Cphys, C, N, Nphys, R, S,
+                         Ho, Wo, stride, pad_h, pad_w, dil, stream())
+                dy.record_stream(side)
+                x.record_stream(side)
+                _WGRAD_PENDING[0] = True
+                if not _JOIN_QUEUED[0]:       # when this backward pass ends, the caller's stream waits for the side stream
+                    _JOIN_QUEUED[0] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(_join_at_end_of_backward)
                 notify_grad(weight)
                 dw = None
-            elif dw.dtype != weight.dtype:
-                dw = dw.to(weight.dtype)
+            else:
+                ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
+                dw = sink if sink is not None else torch.empty((N, C, R, S), dtype=torch.float32, device=x.device)
+                call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), dt(x), B, H, W, Cphys, C, N, Nphys, R, S, Ho, Wo,
+                     stride, pad_h, pad_w, dil, stream())
+                if sink is not None:
+                    notify_grad(weight)
+                    dw = None
+                elif dw.dtype != weight.dtype:
+                    dw = dw.to(weight.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
             from .ops import _stats_fwd
             nslab, sws = _stats_fwd(dy, None)

@@ -148,8 +148,10 @@ class GradSync:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
+        from . import conv
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
+            conv.join_wgrad_stream(self.side)        # the bucket's weight gradients are written on the wgrad stream
             self.works.append(dist.all_reduce(self.opt.flat_g[lo:hi], group=self.group, async_op=True))
 
     def begin(self):
@@ -160,6 +162,8 @@ class GradSync:
 
     def finish(self):
         """Blocks the compute stream until every bucket has been reduced; returns the 1/world scale."""
+        from . import conv
+        conv.join_wgrad_stream()                     # weight gradients are computed on a second stream (mrfp_amd/conv.py)
         if not self.enabled:
             return 1.0
         for b, n in enumerate(self.pending):        # buckets whose tensors got no gradient this step
@@ -206,6 +210,8 @@ class Trainer:
             return self._graph_step(img, label)
         loss = self._fwd_bwd(img, label)
         gscale = self.sync.finish()
+        from . import conv
+        conv.join_wgrad_stream()                       # weight gradients are computed on a second stream
         self.opt.step(gscale / self.loss_scale)
         return loss
 
@@ -247,6 +253,8 @@ class Trainer:
                 with torch.cuda.stream(side):           # eager warm-up on a side stream (lazy tables, attributes, packs)
                     loss = self._fwd_bwd(static_img, static_lab)
                 torch.cuda.current_stream().wait_stream(side)
+                from . import conv
+                conv.join_wgrad_stream()
                 self.opt.step(1.0 / self.loss_scale)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
