@@ -245,12 +245,17 @@ int mrfp_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float
  * reference's model -- nearest arithmetic: dataloaders.py:24-79; semantics are build-defined):
  *   F = rfft2(x[b,:,:,c]); ratio = band ? ((1-lam)|F| + lam|F_partner|)/|F| : 1; y = irfft2(F*ratio)
  *   band = (min(kh,H-kh)^2 + kw^2 <= radius^2), complemented when high != 0; partner = perm[b].
- * S, S3: scratch spectra of mrfp_fourier_spectrum_bytes() bytes each; ratio (optional, float
- * [B,H,W/2+1,C]) is written (load_ratio = 0) or read (load_ratio = 1: the backward pass applies the same
- * detached ratio to the gradient).  twH / twW: float2 tables exp(-2 pi i t/N), t < N, for N = H and N = W.
+ * Ws = mrfp_fourier_stored_bins(H, W, radius, high) is the number of bins along W the scratch spectra hold: W/2+1 in
+ * general; floor(radius)+1 for a LOW band on the register path, where the ratio differs from 1 only in the columns
+ * kw <= radius, so only those columns are transformed and y = x + irfft2(F*(ratio-1)) (same arithmetic, 2.5x less
+ * HBM traffic).  S, S3: scratch spectra, float2 [B,H,Ws,C] each (mrfp_fourier_spectrum_bytes() is the upper bound);
+ * ratio (optional, float [B,H,Ws,C]) is written (load_ratio = 0) or read (load_ratio = 1: the backward pass applies
+ * the same detached ratio to the gradient; pass the forward call's radius and high, they fix Ws).
+ * twH / twW: float2 tables exp(-2 pi i t/N), t < N, for N = H and N = W.
  * H, W of the form 2^a 3^b, <= 512, W even; C % 16 == 0.
  * ------------------------------------------------------------------------------------------- */
 int64_t mrfp_fourier_spectrum_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
+int64_t mrfp_fourier_stored_bins(int64_t H, int64_t W, float radius, int high);
 int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void* S3, float* ratio, int load_ratio,
                      const void* twH, const void* twW, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
                      float radius, float lam, int high, void* stream);

@@ -37,6 +37,8 @@ struct FftP {
     int radix[kMaxStages];
     float radius2, lam, scale;
     int high, load_ratio;
+    int Ws;               // stored bins along W of S / S3 / ratio: Wh (full spectrum) or floor(radius)+1 (band-limited path)
+    int delta;            // band-limited path: S3 holds F*(ratio-1) and the inverse row pass writes x + irfft(.)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -310,11 +312,11 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_fwd_kernel(FftP p) {
     }
     two_step<N1, N2>(a, b, lds, p.tw, ch, sub);
     if (sub < N1) {
-        float2* dst = p.S + (size_t)line * p.Wh * C + cg * kCB + ch;
+        float2* dst = p.S + (size_t)line * p.Ws * C + cg * kCB + ch;
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
             const int kw = sub + N1 * k2;
-            if (kw < p.Wh) dst[(size_t)kw * C] = b[k2];
+            if (kw < p.Ws) dst[(size_t)kw * C] = b[k2];
         }
     }
 }
@@ -329,14 +331,24 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_inv_kernel(FftP p) {
     if (!decode_wg(p.B * p.H, p.C / kCB, line, cg)) return;
     const size_t C = p.C;
     constexpr int N = N1 * N2, WH = N / 2 + 1, NSUB = two_nt(N1, N2) / kCB;
-    // the half spectrum is fetched once; the mirrored half of the Hermitian extension comes out of LDS
+    const int Ws = p.Ws;                                                 // stored bins (<= WH); the others are zero
+    // the stored bins are fetched once; the mirrored half of the Hermitian extension comes out of LDS
     {
-        const float2* src = p.S3 + (size_t)line * WH * C + cg * kCB + ch;
+        const float2* src = p.S3 + (size_t)line * Ws * C + cg * kCB + ch;
 #pragma unroll
         for (int i = 0; i < (WH + NSUB - 1) / NSUB; ++i) {
             const int k = sub + i * NSUB;
-            if (k < WH) stage[k * kCB + ch] = src[(size_t)k * C];
+            if (k < Ws) stage[k * kCB + ch] = src[(size_t)k * C];
         }
+    }
+    float xin[N2];
+    if (p.delta && sub < N1) {                                           // band-limited path: y = x + correction
+        const T* xs = reinterpret_cast<const T*>(p.x) + (size_t)line * p.W * C + cg * kCB + ch;
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) xin[k2] = to_f(xs[(size_t)(sub + N1 * k2) * C]);
+    } else {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) xin[k2] = 0.f;
     }
     __syncthreads();
     float2 a[N1], b[N2];
@@ -344,9 +356,10 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_inv_kernel(FftP p) {
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) {
             const int k = n1 * N2 + sub;
-            float2 v;
-            if (k < WH) { v = stage[k * kCB + ch]; v.y = -v.y; }       // conj(F[k])
-            else v = stage[(N - k) * kCB + ch];                          // conj(conj(F[N-k]))
+            const int km = k < Ws ? k : N - k;                           // k >= Ws: mirrored bin (>= 1)
+            float2 v = stage[(km < Ws ? km : 0) * kCB + ch];
+            if (k < Ws) v.y = -v.y;                                      // conj(F[k]);  mirrored: conj(conj(F[N-k]))
+            if (km >= Ws) v = make_float2(0.f, 0.f);                     // outside the stored band
             a[n1] = v;
         }
     }
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_inv_kernel(FftP p) {
     if (sub < N1) {
         T* dst = reinterpret_cast<T*>(p.y) + (size_t)line * p.W * C + cg * kCB + ch;
 #pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) dst[(size_t)(sub + N1 * k2) * C] = from_f<T>(b[k2].x * p.scale);
+        for (int k2 = 0; k2 < N2; ++k2) dst[(size_t)(sub + N1 * k2) * C] = from_f<T>(xin[k2] + b[k2].x * p.scale);
     }
 }
 
@@ -364,10 +377,10 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
     float2* lds = reinterpret_cast<float2*>(smem);
     const int ch = threadIdx.x % kCB, sub = threadIdx.x / kCB;
     int line, cg;
-    if (!decode_wg(p.B * p.Wh, p.C / kCB, line, cg)) return;
-    const int b = line / p.Wh, kw = line - b * p.Wh;
-    const size_t C = p.C, hs = (size_t)p.Wh * C;
-    const size_t off = ((size_t)b * p.H * p.Wh + kw) * C + cg * kCB + ch;
+    if (!decode_wg(p.B * p.Ws, p.C / kCB, line, cg)) return;
+    const int b = line / p.Ws, kw = line - b * p.Ws;
+    const size_t C = p.C, hs = (size_t)p.Ws * C;
+    const size_t off = ((size_t)b * p.H * p.Ws + kw) * C + cg * kCB + ch;
     float2 a[N1], F[N2];
     if (sub < N2) {
         const float2* own = p.S + off;
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
         __syncthreads();                                   // step B of the own column has left the exchange buffer
         if (sub < N2) {
             const int64_t pb = p.perm ? p.perm[b] : b;
-            const float2* par = p.S + ((size_t)pb * p.H * p.Wh + kw) * C + cg * kCB + ch;
+            const float2* par = p.S + ((size_t)pb * p.H * p.Ws + kw) * C + cg * kCB + ch;
 #pragma unroll
             for (int n1 = 0; n1 < N1; ++n1) a[n1] = par[(size_t)(n1 * N2 + sub) * hs];
         }
@@ -413,8 +426,12 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) rat[(size_t)(sub + N1 * k2) * hs] = rr[k2];
         }
+        const float one = p.delta ? 1.f : 0.f;                  // band-limited path: only the change F*(ratio-1) goes back
 #pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) F[k2] = make_float2(F[k2].x * rr[k2], -F[k2].y * rr[k2]);   // conj for the inverse
+        for (int k2 = 0; k2 < N2; ++k2) {
+            const float m = rr[k2] - one;
+            F[k2] = make_float2(F[k2].x * m, -F[k2].y * m);     // conj for the inverse
+        }
     }
     // inverse along H: the register layout (thread k1 owns k = N1*k2 + k1) is the INPUT layout of the transposed
     // two-step transform, so it starts without an exchange
@@ -445,7 +462,7 @@ static int launch_fast_pass(FftP p, int pass, const float2* tw, hipStream_t st) 
     p.N = TS::N;
     p.tw = tw;
     if (pass == 0) return launch_two(fft_rows_fwd_kernel<T, N1, N2>, p, p.B * p.H, TS::NT, TS::LDS, st);
-    if (pass == 1) return launch_two(fft_cols_mix_kernel<N1, N2>, p, p.B * p.Wh, TS::NT, TS::LDS, st);
+    if (pass == 1) return launch_two(fft_cols_mix_kernel<N1, N2>, p, p.B * p.Ws, TS::NT, TS::LDS, st);
     return launch_two(fft_rows_inv_kernel<T, N1, N2>, p, p.B * p.H, TS::NT, TS::LDS + (TS::N / 2 + 1) * kCB * (int)sizeof(float2), st);
 }
 
@@ -469,11 +486,28 @@ static bool has_fast_plan(int n) {
     return n == 32 || n == 48 || n == 64 || n == 96 || n == 128 || n == 192 || n == 256 || n == 384 || n == 512;
 }
 
-template <typename T>
-static int run_mix(FftP p, const float2* twH, const float2* twW, hipStream_t st) {
+static int fft_generic() {
     static int generic = -1;
     if (generic < 0) { const char* e = getenv("MRFP_FFT_GENERIC"); generic = e ? atoi(e) : 0; }
-    if (!generic && has_fast_plan(p.H) && has_fast_plan(p.W)) {
+    return generic;
+}
+static int fft_full() {          // MRFP_FFT_FULL=1: full half spectrum even for a low band (A/B against the band-limited path)
+    static int full = -1;
+    if (full < 0) { const char* e = getenv("MRFP_FFT_FULL"); full = e ? atoi(e) : 0; }
+    return full;
+}
+// bins along W that S / S3 / ratio hold.  Low band on the register path: the ratio differs from 1 only for
+// kw <= radius, so only those columns of the spectrum are ever formed (y = x + irfft2(F*(ratio-1))).
+static int stored_bins(int64_t H, int64_t W, float radius, int high) {
+    const int Wh = (int)(W / 2 + 1);
+    if (high || fft_generic() || fft_full() || !has_fast_plan((int)H) || !has_fast_plan((int)W) || !(radius >= 0.f)) return Wh;
+    const float fl = floorf(radius);
+    return fl + 1.f < (float)Wh ? (int)fl + 1 : Wh;
+}
+
+template <typename T>
+static int run_mix(FftP p, const float2* twH, const float2* twW, hipStream_t st) {
+    if (!fft_generic() && has_fast_plan(p.H) && has_fast_plan(p.W)) {
         int rc;
         if ((rc = fast_pass<T>(p, p.W, 0, twW, st))) return rc;
         if ((rc = fast_pass<T>(p, p.H, 1, twH, st))) return rc;
@@ -494,6 +528,11 @@ extern "C" {
 
 int64_t mrfp_fourier_spectrum_bytes(int64_t B, int64_t H, int64_t W, int64_t C) { return B * H * (W / 2 + 1) * C * 8; }
 
+int64_t mrfp_fourier_stored_bins(int64_t H, int64_t W, float radius, int high) {
+    if (H < 2 || W < 2) return 0;
+    return stored_bins(H, W, radius, high);
+}
+
 int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void* S3, float* ratio, int load_ratio,
                      const void* twH, const void* twW, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
                      float radius, float lam, int high, void* stream) {
@@ -505,6 +544,8 @@ int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void*
     p.x = x; p.y = y; p.S = (float2*)S; p.S3 = (float2*)S3; p.ratio = ratio; p.perm = perm; p.tw = nullptr;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.Wh = (int)(W / 2 + 1); p.C = (int)C; p.N = 0; p.nstages = 0;
     p.radius2 = radius * radius; p.lam = lam; p.scale = 1.0f / (float)(H * W); p.high = high; p.load_ratio = load_ratio;
+    p.Ws = stored_bins(H, W, radius, high);
+    p.delta = p.Ws < p.Wh;
     if (dtype == MRFP_F32) return run_mix<float>(p, (const float2*)twH, (const float2*)twW, (hipStream_t)stream);
     if (dtype == MRFP_BF16) return run_mix<bf16>(p, (const float2*)twH, (const float2*)twW, (hipStream_t)stream);
     if (dtype == MRFP_F16) return run_mix<f16>(p, (const float2*)twH, (const float2*)twW, (hipStream_t)stream);

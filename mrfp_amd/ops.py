@@ -839,32 +839,33 @@ class _FourierMix(torch.autograd.Function):
         x = _chk(x)
         B, C, H, W = x.shape
         dev = x.device
-        nbytes = int(_lib.lib().mrfp_fourier_spectrum_bytes(B, H, W, C))
-        S = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        S3 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        ratio = torch.empty(B * H * (W // 2 + 1) * C, dtype=torch.float32, device=dev)
+        # bins along W the spectra / ratio hold: W/2+1, or floor(radius)+1 on the band-limited (low band) path
+        ws = int(_lib.lib().mrfp_fourier_stored_bins(H, W, float(radius), int(bool(high))))
+        S = torch.empty(B * H * ws * C * 8, dtype=torch.uint8, device=dev)
+        S3 = torch.empty(B * H * ws * C * 8, dtype=torch.uint8, device=dev)
+        ratio = torch.empty(B * H * ws * C, dtype=torch.float32, device=dev)
         y = empty_cl(B, C, H, W, x.dtype, dev)
         perm = perm.to(device=dev, dtype=torch.int64).contiguous()
         twH, twW = _twiddles(H, str(dev)), _twiddles(W, str(dev))
         call("mrfp_fourier_mix", ptr(x), ptr(y), ptr(perm), ptr(S), ptr(S3), ptr(ratio), 0, ptr(twH), ptr(twW), dt(x),
              B, H, W, C, float(radius), float(lam), int(bool(high)), stream())
         ctx.save_for_backward(ratio)
-        ctx.dims = (B, C, H, W)
+        ctx.dims = (B, C, H, W, ws, float(radius), int(bool(high)))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (ratio,) = ctx.saved_tensors
         dy = _chk(dy, "dy")
-        B, C, H, W = ctx.dims
+        B, C, H, W, ws, radius, high = ctx.dims
         dev = dy.device
-        nbytes = int(_lib.lib().mrfp_fourier_spectrum_bytes(B, H, W, C))
-        S = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        S3 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        S = torch.empty(B * H * ws * C * 8, dtype=torch.uint8, device=dev)
+        S3 = torch.empty(B * H * ws * C * 8, dtype=torch.uint8, device=dev)
         dx = empty_cl(B, C, H, W, dy.dtype, dev)
         twH, twW = _twiddles(H, str(dev)), _twiddles(W, str(dev))
+        # same radius / band as the forward call: they fix the layout of the saved ratio
         call("mrfp_fourier_mix", ptr(dy), ptr(dx), None, ptr(S), ptr(S3), ptr(ratio), 1, ptr(twH), ptr(twW), dt(dy),
-             B, H, W, C, 0.0, 0.0, 0, stream())
+             B, H, W, C, radius, 0.0, high, stream())
         return dx, None, None, None, None
 
 

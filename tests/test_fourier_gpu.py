@@ -21,7 +21,11 @@ def relerr(a, b):
                                                    # two-step register path: every planned line length
                                                    ((2, 16, 192, 192), 16.0, 1.0, False), ((2, 32, 128, 256), 20.0, 0.6, True),
                                                    ((1, 16, 384, 512), 16.0, 1.0, False), ((2, 16, 32, 48), 5.0, 1.0, True),
-                                                   ((3, 16, 256, 64), 16.0, 0.3, True)])
+                                                   ((3, 16, 256, 64), 16.0, 0.3, True),
+                                                   # band-limited low-band path (floor(radius)+1 stored columns): one bin,
+                                                   # fractional radius, a radius past the last column (full spectrum)
+                                                   ((2, 16, 64, 64), 0.0, 1.0, False), ((3, 32, 64, 128), 3.5, 0.8, False),
+                                                   ((2, 16, 32, 48), 30.0, 1.0, False), ((2, 48, 128, 96), 24.0, 1.0, False)])
 def test_fourier_amplitude_mix(dtype, shape, radius, lam, high):
     from mrfp_amd import ops
     B, C, H, W = shape

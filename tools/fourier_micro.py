@@ -52,6 +52,7 @@ def main():
             print(json.dumps({"op": "fourier_mix", "dtype": str(dtype).split(".")[-1], "band": "high" if high else "low",
                               "shape": [B, C, H, W], "ms": round(ms, 4), "algorithmic_GBps": round(alg / ms / 1e6, 1),
                               "frac_of_hbm_peak": round(alg / (ms * 1e-3) / HBM_PEAK, 4),
+                              "stored_bins": int(_lib.lib().mrfp_fourier_stored_bins(H, W, 16.0, high)),
                               "path": "generic" if os.environ.get("MRFP_FFT_GENERIC") == "1" else "two-step"}), flush=True)
 
 
