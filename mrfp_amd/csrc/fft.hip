@@ -288,6 +288,12 @@ __device__ __forceinline__ void two_step(float2 (&a)[N1], float2 (&b)[N2], float
     }
 }
 
+static int fft_nopair() {        // MRFP_FFT_NOPAIR=1: band-limited row passes one channel per transform (A/B)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRFP_FFT_NOPAIR"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 // workgroup id -> (line, channel group): the channel groups of one line are consecutive on one XCD
 __device__ __forceinline__ bool decode_wg(int nlines, int ncg, int& line, int& cg) {
     const int wg = blockIdx.x, xcd = wg & 7, i = wg >> 3;
@@ -368,6 +374,102 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_inv_kernel(FftP p) {
         T* dst = reinterpret_cast<T*>(p.y) + (size_t)line * p.W * C + cg * kCB + ch;
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) dst[(size_t)(sub + N1 * k2) * C] = from_f<T>(xin[k2] + b[k2].x * p.scale);
+    }
+}
+
+// ---- band-limited row passes on CHANNEL PAIRS ---------------------------------------------------
+// Two real lines ride in one complex transform (z = x_even + i x_odd): half the butterflies per element and 4/8-byte
+// instead of 2/4-byte activation accesses.  A thread is (pair < 16, sub); a tile is 32 channels (C % 32 == 0).
+// Forward: Z = FFT(z); the stored bins kw < Ws need Z[kw] and Z[N-kw] (X_even = (Z[k] + conj Z[N-k])/2,
+// X_odd = -i (Z[k] - conj Z[N-k])/2), exchanged through the (by then free) LDS buffer; S keeps its [B,H,Ws,C] layout.
+template <typename T, int N1, int N2>
+__global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_fwd_pair_kernel(FftP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lds = reinterpret_cast<float2*>(smem);
+    const int pr = threadIdx.x % kCB, sub = threadIdx.x / kCB;
+    int line, cg;
+    if (!decode_wg(p.B * p.H, p.C / (2 * kCB), line, cg)) return;
+    const size_t C = p.C;
+    constexpr int N = N1 * N2, NT = two_nt(N1, N2);
+    const int Ws = p.Ws;
+    float2 a[N1], b[N2];
+    if (sub < N2) {
+        const T* src = reinterpret_cast<const T*>(p.x) + (size_t)line * p.W * C + cg * 2 * kCB + 2 * pr;
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            float v[2];
+            load_f<T, 2>(src + (size_t)(n1 * N2 + sub) * C, v);
+            a[n1] = make_float2(v[0], v[1]);
+        }
+    }
+    two_step<N1, N2>(a, b, lds, p.tw, pr, sub);
+    __syncthreads();                                       // every step-B read of the exchange buffer is done
+    if (sub < N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) {
+            const int k = sub + N1 * k2;                   // slot: k < Ws -> k ; k > N-Ws -> Ws + (N-k) - 1
+            if (k < Ws) lds[k * kCB + pr] = b[k2];
+            else if (k > N - Ws) lds[(Ws + N - k - 1) * kCB + pr] = b[k2];
+        }
+    }
+    __syncthreads();
+    float* dst = reinterpret_cast<float*>(p.S + (size_t)line * Ws * C + cg * 2 * kCB + 2 * pr);
+    for (int k = sub; k < Ws; k += NT / kCB) {
+        const int km = k == 0 ? 0 : N - k;
+        const float2 zk = lds[k * kCB + pr];
+        const float2 zm = lds[(km < Ws ? km : Ws + k - 1) * kCB + pr];
+        VecT<float, 4> o;
+        o.v[0] = 0.5f * (zk.x + zm.x);  o.v[1] = 0.5f * (zk.y - zm.y);      // even channel
+        o.v[2] = 0.5f * (zk.y + zm.y);  o.v[3] = -0.5f * (zk.x - zm.x);     // odd channel
+        *reinterpret_cast<VecT<float, 4>*>(dst + (size_t)k * C * 2) = o;
+    }
+}
+
+// Inverse: Z[k] = D_even[k] + i D_odd[k] (k < Ws), Z[N-k] = conj D_even[k] + i conj D_odd[k], zero elsewhere;
+// o = FFT(conj Z) -> the even line is Re o, the odd line is -Im o;  y = x + line / (H W).
+template <typename T, int N1, int N2>
+__global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_inv_pair_kernel(FftP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lds = reinterpret_cast<float2*>(smem);
+    float4* stage = reinterpret_cast<float4*>(lds + TwoStep<N1, N2>::LDS / (int)sizeof(float2));   // [Ws][16 pairs]
+    const int pr = threadIdx.x % kCB, sub = threadIdx.x / kCB;
+    int line, cg;
+    if (!decode_wg(p.B * p.H, p.C / (2 * kCB), line, cg)) return;
+    const size_t C = p.C;
+    constexpr int N = N1 * N2, NT = two_nt(N1, N2);
+    const int Ws = p.Ws;
+    {
+        const float* src = reinterpret_cast<const float*>(p.S3 + (size_t)line * Ws * C + cg * 2 * kCB + 2 * pr);
+        for (int k = sub; k < Ws; k += NT / kCB) stage[k * kCB + pr] = *reinterpret_cast<const float4*>(src + (size_t)k * C * 2);
+    }
+    float xin[N2][2];
+    if (sub < N1) {
+        const T* xs = reinterpret_cast<const T*>(p.x) + (size_t)line * p.W * C + cg * 2 * kCB + 2 * pr;
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) load_f<T, 2>(xs + (size_t)(sub + N1 * k2) * C, xin[k2]);
+    }
+    __syncthreads();
+    float2 a[N1], b[N2];
+    if (sub < N2) {
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const int k = n1 * N2 + sub;
+            const int km = k < Ws ? k : N - k;
+            const float4 d = stage[(km < Ws ? km : 0) * kCB + pr];        // (D_even, D_odd) of bin km
+            float2 v = k < Ws ? make_float2(d.x - d.w, -d.y - d.z)         // conj(D_even + i D_odd)
+                              : make_float2(d.x + d.w, d.y - d.z);         // conj(conj D_even + i conj D_odd)
+            if (km >= Ws) v = make_float2(0.f, 0.f);
+            a[n1] = v;
+        }
+    }
+    two_step<N1, N2>(a, b, lds, p.tw, pr, sub);
+    if (sub < N1) {
+        T* dst = reinterpret_cast<T*>(p.y) + (size_t)line * p.W * C + cg * 2 * kCB + 2 * pr;
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) {
+            const float o[2] = {xin[k2][0] + b[k2].x * p.scale, xin[k2][1] - b[k2].y * p.scale};
+            store_f<T, 2>(dst + (size_t)(sub + N1 * k2) * C, o);
+        }
     }
 }
 
@@ -461,6 +563,24 @@ static int launch_fast_pass(FftP p, int pass, const float2* tw, hipStream_t st) 
     using TS = TwoStep<N1, N2>;
     p.N = TS::N;
     p.tw = tw;
+    if (p.delta && p.C % (2 * kCB) == 0 && pass != 1 && !fft_nopair()) {     // band-limited row passes on channel pairs
+        const FftP& q = p;
+        const unsigned grid = (unsigned)(((p.B * p.H + 7) / 8) * 8 * (p.C / (2 * kCB)));
+        if (pass == 0) {
+            if (TS::LDS > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_fwd_pair_kernel<T, N1, N2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, TS::LDS);
+            hipLaunchKernelGGL((fft_rows_fwd_pair_kernel<T, N1, N2>), dim3(grid), dim3((unsigned)TS::NT), TS::LDS, st, q);
+        } else {
+            const int lds = TS::LDS + p.Ws * kCB * (int)sizeof(float4);
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_inv_pair_kernel<T, N1, N2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((fft_rows_inv_pair_kernel<T, N1, N2>), dim3(grid), dim3((unsigned)TS::NT), lds, st, q);
+        }
+        MRFP_LAUNCH_CHECK();
+        return 0;
+    }
     if (pass == 0) return launch_two(fft_rows_fwd_kernel<T, N1, N2>, p, p.B * p.H, TS::NT, TS::LDS, st);
     if (pass == 1) return launch_two(fft_cols_mix_kernel<N1, N2>, p, p.B * p.Ws, TS::NT, TS::LDS, st);
     return launch_two(fft_rows_inv_kernel<T, N1, N2>, p, p.B * p.H, TS::NT, TS::LDS + (TS::N / 2 + 1) * kCB * (int)sizeof(float2), st);
