@@ -13,7 +13,8 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so both sides 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mrfp_hip.h")
-LIBPATH = os.path.join(_HERE, "csrc", "libmrfp_hip.so")
+# MRFP_HIP_LIB: an alternative build of the same library (A/B runs of build-time kernel variants on one GPU box)
+LIBPATH = os.environ.get("MRFP_HIP_LIB") or os.path.join(_HERE, "csrc", "libmrfp_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
