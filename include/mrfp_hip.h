@@ -241,6 +241,24 @@ int mrfp_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float
                   float weight_decay, float gscale, int first, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Group whitening passes (groups of 16 channels; reference network/sync_switchwhiten.py:20-26, 161-170:
+ * in_data.mean(-1), bmm(in_data, in_data^T) per group; :217 bmm(wm, in_data); network/instance_whitening.py):
+ *   mrfp_group_moments: M[b,g,i,j] = sum_p a[b,p,16g+i] * b[b,p,16g+j]  (fp32 [B,C/16,16,16]) and, when sum_a != NULL,
+ *     sum_a[b,c] = sum_p a[b,p,c] -- one read of a and of b (a == b: second moments of the forward pass; a = dy,
+ *     b = x: gradient of the whitening matrix and of the shift).  ws: mrfp_group_moments_ws_bytes() bytes of scratch
+ *     (per-workgroup fp32 partials, combined in fp64 in a fixed order).
+ *   mrfp_group_apply:   y[b,p,16g+i] = sum_j Wm[b,g,i,j] x[b,p,16g+j] (+ sum_j Vm[b,g,i,j] z[b,p,16g+j]) + shift[b,16g+i]
+ *     (z, Vm both NULL or both given; shift optional) -- forward: the folded whitening matrix and offset; backward:
+ *     dx = Wm^T dy + (dM + dM^T) x + dmean/HW in one pass.
+ * a, b, x, z, y: [B,HW,C] activations (dtype); C % 16 == 0, C <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+int64_t mrfp_group_moments_ws_bytes(int64_t B, int64_t HW, int64_t C);
+int mrfp_group_moments(const void* a, const void* b, float* M, float* sum_a, void* ws, int dtype, int64_t B, int64_t HW,
+                       int64_t C, void* stream);
+int mrfp_group_apply(const void* x, const float* Wm, const void* z, const float* Vm, const float* shift, void* y, int dtype,
+                     int64_t B, int64_t HW, int64_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fourier amplitude perturbation (north_star extension; no function of this kind exists in the
  * reference's model -- nearest arithmetic: dataloaders.py:24-79; semantics are build-defined):
  *   F = rfft2(x[b,:,:,c]); ratio = band ? ((1-lam)|F| + lam|F_partner|)/|F| : 1; y = irfft2(F*ratio)

@@ -1,0 +1,237 @@
+// whiten.hip -- group whitening passes over an NHWC activation (groups of 16 channels): the heavy parts of the
+// switchable / instance whitening options (reference network/sync_switchwhiten.py:20-26, 161-170 "in_data.mean",
+// "bmm(x, x^T)" per group; 217 "bmm(wm, in_data)"; network/instance_whitening.py).
+//
+//   group_moments   M[b,g] = sum_p a_g(p) b_g(p)^T  (16x16 per group, fp32) and sum_p a(p)  -- ONE read of a and b
+//                   (a == b: the second moments of the forward pass; a = dy, b = x: the gradient of the whitening matrix)
+//   group_apply     y(p) = Wm[b,g] x_g(p) (+ Vm[b,g] z_g(p)) + shift[b]                     -- one read (two), one write
+//                   (forward: the folded whitening matrix; backward: dx = Wm^T dy + (dM + dM^T) x + dmu/HW in one pass)
+//
+// Both are HBM-bound streaming kernels.  A thread owns (pixel slot, group g, row quarter q): it loads the 16 channels
+// of its group (two 16-byte loads for the 16-bit types; consecutive threads read consecutive 32/64-byte runs, so a wave
+// covers whole pixels) and keeps a 4x16 block of the 16x16 product / matrix in registers: 64 FMAs per 16 channels read.
+// Reduction over pixels: registers -> LDS across the pixel slots of the workgroup -> one fp32 partial per workgroup ->
+// fp64 combination in a finalize kernel (fixed order: bitwise reproducible).
+#include "common.hpp"
+
+namespace mrfp {
+
+constexpr int kG = 16;                 // channels per whitening group (reference num_pergroup = 16)
+constexpr int kPart = 4 * kG + 4;      // floats a thread contributes: its 4x16 block + its 4 channel sums
+
+template <typename T>
+__device__ __forceinline__ void load16(const T* p, float (&o)[16]) {
+    constexpr int V = FullVec<T>::value;             // 8 (16-bit) / 4 (fp32) elements per 16-byte load
+#pragma unroll
+    for (int i = 0; i < 16 / V; ++i) {
+        float t[V];
+        load_f<T, V>(p + i * V, t);
+#pragma unroll
+        for (int u = 0; u < V; ++u) o[i * V + u] = t[u];
+    }
+}
+
+struct WhitenGeom {
+    int tpp;     // threads per pixel = C / 4
+    int ppi;     // pixel slots per workgroup = 256 / tpp
+    int nch;     // pixel chunks (workgroups) per image
+    int per;     // pixels per chunk (multiple of ppi)
+};
+static WhitenGeom whiten_geom(int64_t B, int64_t HW, int64_t C) {
+    WhitenGeom g;
+    g.tpp = (int)(C / 4);
+    g.ppi = kThreads / g.tpp;
+    int64_t want = 2048 / (B > 0 ? B : 1);                       // ~2048 workgroups over the chip
+    if (want < 1) want = 1;
+    int64_t per = (HW + want - 1) / want;
+    const int64_t minper = 8 * g.ppi;                             // at least 8 iterations per workgroup
+    if (per < minper) per = minper;
+    per = (per + g.ppi - 1) / g.ppi * g.ppi;
+    g.per = (int)per;
+    g.nch = (int)((HW + per - 1) / per);
+    return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void group_moments_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                                  float* __restrict__ part, int HW, int C, int tpp, int ppi,
+                                                                  int per) {
+    __shared__ float red[kThreads * 17];
+    const int slot = threadIdx.x / tpp, tq = threadIdx.x - slot * tpp;
+    const int g = tq >> 2, q = tq & 3;
+    const int img = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * per, p1 = min(p0 + per, HW);
+    const bool live = slot < ppi;
+    float acc[4][16], s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    }
+    const size_t base = (size_t)img * HW * C + g * kG;
+#pragma unroll 2
+    for (int p = live ? p0 + slot : p1; p < p1; p += ppi) {
+        float av[4], bv[16];
+        load_f<T, 4>(a + base + (size_t)p * C + 4 * q, av);
+        load16<T>(b + base + (size_t)p * C, bv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ai = av[i];
+            s[i] += ai;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][j] = fmaf(ai, bv[j], acc[i][j]);
+        }
+    }
+    // across the pixel slots of the workgroup, 17 values at a time through LDS
+    float* out = part + ((size_t)img * gridDim.x + chunk) * (size_t)tpp * kPart;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) red[(slot * tpp + tq) * 17 + j] = acc[r][j];
+            red[(slot * tpp + tq) * 17 + 16] = s[r];
+        }
+        __syncthreads();
+        for (int v = threadIdx.x; v < tpp * 17; v += kThreads) {
+            const int t = v / 17, e = v - t * 17;
+            float sum = 0.f;
+            for (int sl = 0; sl < ppi; ++sl) sum += red[(sl * tpp + t) * 17 + e];
+            out[(size_t)t * kPart + (e < 16 ? r * 16 + e : 64 + r)] = sum;
+        }
+    }
+}
+
+// part [B][nch][tpp][68] -> M [B][C/16][16][16], sum_a [B][C]   (fp64 combination, fixed order)
+__global__ __launch_bounds__(kThreads) void group_moments_finalize_kernel(const float* __restrict__ part, int nch, int tpp,
+                                                                           int C, float* __restrict__ M, float* __restrict__ sum_a) {
+    const int img = blockIdx.y;
+    const int v = blockIdx.x * kThreads + threadIdx.x;
+    if (v >= tpp * kPart) return;
+    const int t = v / kPart, e = v - t * kPart;
+    double acc = 0.0;
+    const float* src = part + (size_t)img * nch * tpp * kPart + v;
+    for (int c = 0; c < nch; ++c) acc += (double)src[(size_t)c * tpp * kPart];
+    const int g = t >> 2, q = t & 3;
+    if (e < 64) {
+        const int i = e >> 4, j = e & 15;
+        M[(((size_t)img * (C / kG) + g) * kG + 4 * q + i) * kG + j] = (float)acc;
+    } else if (sum_a) {
+        sum_a[(size_t)img * C + g * kG + 4 * q + (e - 64)] = (float)acc;
+    }
+}
+
+template <typename T, bool TWO>
+__global__ __launch_bounds__(kThreads) void group_apply_kernel(const T* __restrict__ x, const float* __restrict__ Wm,
+                                                                const T* __restrict__ z, const float* __restrict__ Vm,
+                                                                const float* __restrict__ shift, T* __restrict__ y, int HW,
+                                                                int C, int tpp, int ppi, int per) {
+    const int slot = threadIdx.x / tpp, tq = threadIdx.x - slot * tpp;
+    const int g = tq >> 2, q = tq & 3;
+    const int img = blockIdx.y;
+    const int p0 = blockIdx.x * per, p1 = min(p0 + per, HW);
+    if (slot >= ppi) return;
+    float w[4][16], v[TWO ? 4 : 1][16], sh[4];
+    const size_t mb = (((size_t)img * (C / kG) + g) * kG + 4 * q) * kG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sh[i] = shift ? shift[(size_t)img * C + g * kG + 4 * q + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            w[i][j] = Wm[mb + i * kG + j];
+            if (TWO) v[i][j] = Vm[mb + i * kG + j];
+        }
+    }
+    const size_t base = (size_t)img * HW * C + g * kG;
+    for (int p = p0 + slot; p < p1; p += ppi) {
+        float xv[16], zv[16], o[4];
+        load16<T>(x + base + (size_t)p * C, xv);
+        if (TWO) load16<T>(z + base + (size_t)p * C, zv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r = sh[i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) r = fmaf(w[i][j], xv[j], r);
+            if (TWO) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r = fmaf(v[i][j], zv[j], r);
+            }
+            o[i] = r;
+        }
+        store_f<T, 4>(y + base + (size_t)p * C + 4 * q, o);
+    }
+}
+
+static bool whiten_shape_ok(int64_t B, int64_t HW, int64_t C) {
+    return B > 0 && B < 65536 && HW > 0 && HW < (1ll << 31) && C >= kG && C <= 1024 && C % kG == 0;
+}
+
+template <typename T>
+static int run_moments(const void* a, const void* b, float* M, float* sum_a, float* ws, int64_t B, int64_t HW, int64_t C,
+                       hipStream_t st) {
+    const WhitenGeom g = whiten_geom(B, HW, C);
+    hipLaunchKernelGGL((group_moments_kernel<T>), dim3((unsigned)g.nch, (unsigned)B), dim3(kThreads), 0, st, (const T*)a,
+                       (const T*)b, ws, (int)HW, (int)C, g.tpp, g.ppi, g.per);
+    MRFP_LAUNCH_CHECK();
+    const int nv = g.tpp * kPart;
+    hipLaunchKernelGGL(group_moments_finalize_kernel, dim3((unsigned)((nv + kThreads - 1) / kThreads), (unsigned)B),
+                       dim3(kThreads), 0, st, (const float*)ws, g.nch, g.tpp, (int)C, M, sum_a);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int run_apply(const void* x, const float* Wm, const void* z, const float* Vm, const float* shift, void* y, int64_t B,
+                     int64_t HW, int64_t C, hipStream_t st) {
+    const WhitenGeom g = whiten_geom(B, HW, C);
+    const dim3 grid((unsigned)g.nch, (unsigned)B);
+    if (z)
+        hipLaunchKernelGGL((group_apply_kernel<T, true>), grid, dim3(kThreads), 0, st, (const T*)x, Wm, (const T*)z, Vm, shift,
+                           (T*)y, (int)HW, (int)C, g.tpp, g.ppi, g.per);
+    else
+        hipLaunchKernelGGL((group_apply_kernel<T, false>), grid, dim3(kThreads), 0, st, (const T*)x, Wm, (const T*)nullptr,
+                           (const float*)nullptr, shift, (T*)y, (int)HW, (int)C, g.tpp, g.ppi, g.per);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mrfp
+
+using namespace mrfp;
+
+extern "C" {
+
+int64_t mrfp_group_moments_ws_bytes(int64_t B, int64_t HW, int64_t C) {
+    if (!whiten_shape_ok(B, HW, C)) return 0;
+    const WhitenGeom g = whiten_geom(B, HW, C);
+    return B * (int64_t)g.nch * g.tpp * kPart * 4;
+}
+
+int mrfp_group_moments(const void* a, const void* b, float* M, float* sum_a, void* ws, int dtype, int64_t B, int64_t HW,
+                       int64_t C, void* stream) {
+    MRFP_CHECK(a && b && M && ws, "group_moments: null argument");
+    MRFP_CHECK(whiten_shape_ok(B, HW, C), "group_moments: unsupported shape B=%lld HW=%lld C=%lld (C %% 16 == 0, C <= 1024)",
+               (long long)B, (long long)HW, (long long)C);
+    MRFP_CHECK(aligned16(a) && aligned16(b), "group_moments: activations must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return run_moments<float>(a, b, M, sum_a, (float*)ws, B, HW, C, st);
+    if (dtype == MRFP_BF16) return run_moments<bf16>(a, b, M, sum_a, (float*)ws, B, HW, C, st);
+    if (dtype == MRFP_F16) return run_moments<f16>(a, b, M, sum_a, (float*)ws, B, HW, C, st);
+    MRFP_CHECK(false, "group_moments: unknown dtype %d", dtype);
+}
+
+int mrfp_group_apply(const void* x, const float* Wm, const void* z, const float* Vm, const float* shift, void* y, int dtype,
+                     int64_t B, int64_t HW, int64_t C, void* stream) {
+    MRFP_CHECK(x && Wm && y && (!z == !Vm), "group_apply: null argument (z and Vm come together)");
+    MRFP_CHECK(whiten_shape_ok(B, HW, C), "group_apply: unsupported shape B=%lld HW=%lld C=%lld (C %% 16 == 0, C <= 1024)",
+               (long long)B, (long long)HW, (long long)C);
+    MRFP_CHECK(aligned16(x) && aligned16(y) && (!z || aligned16(z)), "group_apply: activations must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_F32) return run_apply<float>(x, Wm, z, Vm, shift, y, B, HW, C, st);
+    if (dtype == MRFP_BF16) return run_apply<bf16>(x, Wm, z, Vm, shift, y, B, HW, C, st);
+    if (dtype == MRFP_F16) return run_apply<f16>(x, Wm, z, Vm, shift, y, B, HW, C, st);
+    MRFP_CHECK(false, "group_apply: unknown dtype %d", dtype);
+}
+
+}  // extern "C"

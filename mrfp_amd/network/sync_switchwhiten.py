@@ -1,9 +1,10 @@
 """Switchable whitening (the `wt_layer` code 5 option): reference network/sync_switchwhiten.py:9-223 and its
 single-process twin network/switchwhiten.py:7-183.
 
-Split of the work: everything that touches the [N,C,H,W] activation runs on the HIP kernels -- plane means
-(statistics kernel), second moments (MFMA "reduce over pixels" GEMM, ops.channel_gram), and the application of
-the whitening matrix (1x1 implicit-GEMM per image, ops.per_image_matmul).  The 16x16 algebra in between
+Split of the work: everything that touches the [N,C,H,W] activation runs on the HIP kernels -- for the reference's
+group size 16 the dedicated group passes of csrc/whiten.hip (sums + 16x16 second moments in one read; folded whitening
+matrix and offset in one read / one write; ops.group_whiten), otherwise plane means (statistics kernel), the full
+Gram (MFMA "reduce over pixels" GEMM, ops.channel_gram) and a 1x1 implicit GEMM per image.  The 16x16 algebra in between
 (softmax blend of batch / instance statistics, trace normalisation, T Newton-Schulz steps, affine folding) is a
 few KB of data and is expressed with torch ops so that autograd provides exactly the reference's backward.
 """
@@ -62,6 +63,7 @@ class SyncSwitchWhiten2d(nn.Module):
             self.register_parameter("bias", None)
         self.register_buffer("running_mean", torch.zeros(self.num_groups, num_pergroup, 1))
         self.register_buffer("running_cov", torch.eye(num_pergroup).unsqueeze(0).repeat(self.num_groups, 1, 1))
+        self.use_group_kernels = True        # False: the generic (any group size) passes, kept for cross-checks
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -82,11 +84,33 @@ class SyncSwitchWhiten2d(nn.Module):
         N, C, H, W = x.shape
         c, g = self.num_pergroup, self.num_groups
         hw = float(H * W)
-        # heavy passes over the activation (HIP): plane means and per-image second moments
+        if c == 16 and C <= 1024 and self.use_group_kernels:
+            # dedicated group passes (csrc/whiten.hip): sums and 16x16 second moments in ONE read of x, the folded
+            # whitening matrix + offset in one read / one write; the backward pass reads (dy, x) twice and writes dx once
+            def algebra(s, M):
+                sq = torch.diagonal(M, dim1=-2, dim2=-1).sum((1, 2))
+                wm, shift = self._transform(s / hw, M, sq, N, C, hw)
+                return wm, shift
+            params = [p for p in (self.sw_mean_weight, self.sw_var_weight, self.weight, self.bias) if p is not None]
+            return ops.group_whiten(x, algebra, params)
+        # other group sizes: plane means + the full C x C Gram on the MFMA "reduce over pixels" GEMM, application as a
+        # per-image 1x1 implicit GEMM
         mu = ops.plane_mean(x)                                   # [N, C]
         gram = ops.channel_gram(x)                               # [N, C, C] = sum_p x x^T
         idx = torch.arange(C, device=x.device).view(g, c)
-        blocks = gram[:, idx.unsqueeze(-1), idx.unsqueeze(-2)]   # [N, g, c, c] diagonal 16x16 blocks
+        blocks = gram[:, idx.unsqueeze(-1), idx.unsqueeze(-2)]   # [N, g, c, c] diagonal blocks
+        sq = torch.diagonal(gram, dim1=1, dim2=2).sum(1)
+        wm, shift = self._transform(mu, blocks, sq, N, C, hw)
+        full = torch.zeros(N, C, C, device=x.device, dtype=torch.float32)
+        full[:, idx.unsqueeze(-1), idx.unsqueeze(-2)] = wm
+        return ops.per_image_matmul(x, full, shift)
+
+    def _transform(self, mu, blocks, sq, N, C, hw):
+        """(plane means [N,C], sum_p x_g x_g^T [N,g,c,c], sum of squares per image [N]) -> folded whitening matrix
+        [N,g,c,c] and offset [N,C]: the 16x16 algebra of reference sync_switchwhiten.py:161-223, a few KB, in torch ops
+        so that autograd yields the reference's backward."""
+        c, g = self.num_pergroup, self.num_groups
+        dev = mu.device
         mean_in = mu.view(N, g, c, 1)
         m2_in = blocks / hw                                      # E[x x^T] per image
         cov_in = m2_in - mean_in @ mean_in.transpose(-1, -2)     # centred instance covariance (/HW, biased)
@@ -105,16 +129,15 @@ class SyncSwitchWhiten2d(nn.Module):
             mean_bn, cov_bn = self.running_mean, self.running_cov
         mean_bn = mean_bn.unsqueeze(0).expand(N, g, c, 1)
         cov_bn = cov_bn.unsqueeze(0).expand(N, g, c, c)
-        eye = torch.eye(c, device=x.device, dtype=torch.float32).view(1, 1, c, c)
+        eye = torch.eye(c, device=dev, dtype=torch.float32).view(1, 1, c, c)
 
         mean_weight = torch.softmax(self.sw_mean_weight, 0)
         var_weight = mean_weight if self.tie_weight else torch.softmax(self.sw_var_weight, 0)
         if self.sw_type in (3, 5):
             # layer statistics over (C, H, W) per sample: mean and UNBIASED variance (x.var(-1))
-            n_el = float(C * H * W)
+            n_el = float(C) * hw
             mean_ln = mu.mean(1).view(N, 1, 1, 1)
-            sq = torch.diagonal(gram, dim1=1, dim2=2).sum(1).view(N, 1, 1, 1)
-            var_ln = (sq - n_el * mean_ln * mean_ln) / (n_el - 1.0)
+            var_ln = (sq.view(N, 1, 1, 1) - n_el * mean_ln * mean_ln) / (n_el - 1.0)
             var_ln = var_ln * eye
         if self.sw_type == 2:
             mean = mean_weight[0] * mean_bn + mean_weight[1] * mean_in
@@ -140,15 +163,13 @@ class SyncSwitchWhiten2d(nn.Module):
             P = 1.5 * P - 0.5 * (P @ P @ P) @ cov_n
         wm = P * rTr.sqrt()                                       # cov^{-1/2}, [N, g, c, c]
 
-        # fold mean and affine into one per-image block-diagonal matrix + offset, apply on the HIP kernel
+        # fold mean and affine into one per-image block-diagonal matrix + offset
         if self.affine:
             wm = wm * self.weight.view(1, g, c, 1)
         shift = -(wm @ mean).view(N, C)
         if self.affine:
             shift = shift + self.bias.view(1, C)
-        full = torch.zeros(N, C, C, device=x.device, dtype=torch.float32)
-        full[:, idx.unsqueeze(-1), idx.unsqueeze(-2)] = wm
-        return ops.per_image_matmul(x, full, shift)
+        return wm, shift
 
 
 class SwitchWhiten2d(SyncSwitchWhiten2d):

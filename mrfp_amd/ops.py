@@ -821,6 +821,117 @@ def per_image_matmul(x, Wm, bias=None):
 
 
 # ------------------------------------------------------------------------------------------
+# group whitening passes (csrc/whiten.hip): groups of 16 channels, one read per statistics pass
+# ------------------------------------------------------------------------------------------
+def _gm_call(a, b, want_sum=True):
+    B, C, H, W = a.shape
+    dev = a.device
+    M = torch.empty(B, C // 16, 16, 16, dtype=torch.float32, device=dev)
+    s = torch.empty(B, C, dtype=torch.float32, device=dev) if want_sum else None
+    nbytes = int(_lib.lib().mrfp_group_moments_ws_bytes(B, H * W, C))
+    if nbytes <= 0:
+        raise _lib.MrfpHipError("group_moments: unsupported shape %s (C %% 16 == 0, C <= 1024)" % (tuple(a.shape),))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    call("mrfp_group_moments", ptr(a), ptr(b), ptr(M), ptr(s), ptr(ws), dt(a), B, H * W, C, stream())
+    return s, M
+
+
+def _ga_call(x, Wm, z=None, Vm=None, shift=None):
+    B, C, H, W = x.shape
+    y = empty_cl(B, C, H, W, x.dtype, x.device)
+    call("mrfp_group_apply", ptr(x), ptr(Wm), ptr(z), ptr(Vm), ptr(shift), ptr(y), dt(x), B, H * W, C, stream())
+    return y
+
+
+class _GroupMoments(torch.autograd.Function):
+    """s[b,c] = sum_p x, M[b,g] = sum_p x_g x_g^T (16x16 per group): in_data.mean / bmm(x, x^T) of reference
+    sync_switchwhiten.py:20-23, 161-165 in one read of x."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        ctx.save_for_backward(x)
+        return _gm_call(x, x)
+
+    @staticmethod
+    def backward(ctx, ds, dM):
+        (x,) = ctx.saved_tensors
+        dM = dM.float()
+        sym = (dM + dM.transpose(-1, -2)).contiguous()
+        return _ga_call(x, sym, shift=ds.float().contiguous())
+
+
+def group_moments(x):
+    return _GroupMoments.apply(x)
+
+
+class _GroupApply(torch.autograd.Function):
+    """y_g(p) = Wm[b,g] x_g(p) + shift[b]: bmm(wm, in_data) of reference sync_switchwhiten.py:217 with the mean and the
+    affine folded in; backward = one transposed apply + one cross-moments pass (dWm = sum_p dy_g x_g^T, dshift = sum_p dy)."""
+
+    @staticmethod
+    def forward(ctx, x, Wm, shift):
+        x = _chk(x)
+        Wm, shift = Wm.float().contiguous(), shift.float().contiguous()
+        ctx.save_for_backward(x, Wm)
+        return _ga_call(x, Wm, shift=shift)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wm = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        dshift, dWm = _gm_call(dy, x)
+        dx = _ga_call(dy, Wm.transpose(-1, -2).contiguous())
+        return dx, dWm, dshift
+
+
+def group_apply(x, Wm, shift):
+    return _GroupApply.apply(x, Wm, shift)
+
+
+class _GroupWhiten(torch.autograd.Function):
+    """moments -> (small algebra, torch autograd) -> apply as ONE node, so that the backward pass touches the activation
+    only twice: cross moments of (dy, x), then dx = Wm^T dy + (dM + dM^T) x + ds in a single pass."""
+
+    @staticmethod
+    def forward(ctx, x, algebra, *params):
+        x = _chk(x)
+        s, M = _gm_call(x, x)
+        with torch.enable_grad():
+            s_l, M_l = s.requires_grad_(True), M.requires_grad_(True)
+            Wm, shift = algebra(s_l, M_l)
+        Wm_c, shift_c = Wm.detach().float().contiguous(), shift.detach().float().contiguous()
+        y = _ga_call(x, Wm_c, shift=shift_c)
+        ctx.save_for_backward(x, Wm_c)
+        ctx.graph = (s_l, M_l, Wm, shift)
+        ctx.params = params
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wm_c = ctx.saved_tensors
+        s_l, M_l, Wm, shift = ctx.graph
+        ctx.graph = None
+        dy = _chk(dy, "dy")
+        dshift, dWm = _gm_call(dy, x)
+        inputs = (s_l, M_l) + tuple(p for p in ctx.params if p.requires_grad)
+        grads = torch.autograd.grad((Wm, shift), inputs, (dWm.to(Wm.dtype), dshift.view_as(shift).to(shift.dtype)),
+                                    allow_unused=True)
+        ds = grads[0] if grads[0] is not None else torch.zeros_like(s_l)
+        dM = grads[1] if grads[1] is not None else torch.zeros_like(M_l)
+        sym = (dM + dM.transpose(-1, -2)).float().contiguous()
+        dx = _ga_call(dy, Wm_c.transpose(-1, -2).contiguous(), z=x, Vm=sym, shift=ds.float().contiguous())
+        it = iter(grads[2:])
+        return (dx, None) + tuple(next(it) if p.requires_grad else None for p in ctx.params)
+
+
+def group_whiten(x, algebra, params):
+    """y = apply(x, *algebra(sum_p x, sum_p x x^T per group)); `algebra(s [B,C], M [B,C/16,16,16]) -> (Wm [B,C/16,16,16],
+    shift [B,C])` is differentiable torch code over a few KB that may use the parameters `params`."""
+    return _GroupWhiten.apply(x, algebra, *params)
+
+
+# ------------------------------------------------------------------------------------------
 # Fourier amplitude perturbation (build-defined extension, DESIGN.md section 8)
 # ------------------------------------------------------------------------------------------
 @lru_cache(maxsize=32)

@@ -77,3 +77,67 @@ def test_resnet_with_wt_layer_5_and_1_runs():
         assert tuple(out.shape) == (2, 512, 2, 2) and torch.isfinite(out).all()
         out.sum().backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in net.named_parameters() if not n.startswith("fc"))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("shape", [(2, 32, 5, 7), (3, 64, 17, 9), (2, 48, 12, 20), (2, 256, 24, 24), (1, 1024, 6, 5)])
+def test_group_moments_and_apply_ops(dtype, tol, shape):
+    """csrc/whiten.hip against plain torch: sums + 16x16 second moments per group, the group matrix application, and
+    both backward passes."""
+    from mrfp_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(*shape, generator=g) + 0.2).to(dtype).float()
+    Wm = torch.randn(B, C // 16, 16, 16, generator=g) * 0.3
+    sh = torch.randn(B, C, generator=g)
+    gy, gs, gM = torch.randn(*shape, generator=g), torch.randn(B, C, generator=g), torch.randn(B, C // 16, 16, 16, generator=g)
+    # torch reference
+    xr = x.clone().requires_grad_(True)
+    Wr, sr = Wm.clone().requires_grad_(True), sh.clone().requires_grad_(True)
+    xg = xr.view(B, C // 16, 16, H * W)
+    s_ref, M_ref = xr.sum((2, 3)), xg @ xg.transpose(-1, -2)
+    y_ref = (Wr @ xg).view(B, C, H, W) + sr.view(B, C, 1, 1)
+    ((s_ref * gs).sum() + (M_ref * gM).sum() + (y_ref * gy.to(dtype).float()).sum()).backward()
+    # HIP
+    xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    Wd, sd = Wm.to(DEV).requires_grad_(True), sh.to(DEV).requires_grad_(True)
+    s, M = ops.group_moments(xd)
+    y = ops.group_apply(xd, Wd, sd)
+    assert relerr(s, s_ref) < tol and relerr(M, M_ref) < tol and relerr(y, y_ref) < tol
+    ((s * gs.to(DEV)).sum() + (M * gM.to(DEV)).sum()).backward()
+    g1 = xd.grad.clone()
+    xd.grad = None
+    y.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    xr2 = x.clone().requires_grad_(True)
+    xg2 = xr2.view(B, C // 16, 16, H * W)
+    ((xr2.sum((2, 3)) * gs).sum() + ((xg2 @ xg2.transpose(-1, -2)) * gM).sum()).backward()
+    assert relerr(g1, xr2.grad) < tol                                     # through the moments
+    assert relerr(xd.grad + g1.float(), xr.grad) < 2 * tol                # apply + moments = the joint reference gradient
+    assert relerr(Wd.grad, Wr.grad) < tol and relerr(sd.grad, sr.grad) < tol
+
+
+@pytest.mark.parametrize("sw_type,tie", [(2, False), (3, True), (5, False)])
+def test_switch_whiten_group_kernels_match_generic_passes(sw_type, tie):
+    """the fused group path (one node: moments -> 16x16 algebra -> apply) against the generic Gram / per-image GEMM path."""
+    from mrfp_amd.network.sync_switchwhiten import SwitchWhiten2d
+    torch.manual_seed(3)
+    x0 = torch.randn(3, 64, 14, 10) * 1.5 + 0.3
+    gy = torch.randn(3, 64, 14, 10)
+    outs = []
+    for fast in (True, False):
+        torch.manual_seed(5)
+        sw = SwitchWhiten2d(64, num_pergroup=16, sw_type=sw_type, T=5, tie_weight=tie).to(DEV)
+        with torch.no_grad():
+            sw.weight.uniform_(0.5, 1.5)
+            sw.bias.uniform_(-0.5, 0.5)
+            sw.sw_mean_weight.uniform_(-0.5, 0.5)
+            if not tie:
+                sw.sw_var_weight.uniform_(-0.5, 0.5)
+        sw.use_group_kernels = fast
+        sw.train()
+        x = x0.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = sw(x)
+        y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        outs.append((y, x.grad, sw.weight.grad, sw.bias.grad, sw.sw_mean_weight.grad, sw.running_mean.clone(), sw.running_cov.clone()))
+    for a, b in zip(*outs):
+        assert relerr(a, b) < 5e-4
