@@ -257,6 +257,11 @@ int mrfp_group_moments(const void* a, const void* b, float* M, float* sum_a, voi
                        int64_t C, void* stream);
 int mrfp_group_apply(const void* x, const float* Wm, const void* z, const float* Vm, const float* shift, void* y, int dtype,
                      int64_t B, int64_t HW, int64_t C, void* stream);
+/* Inverse square root of n 16x16 covariance matrices by T <= 8 Newton-Schulz steps (reference
+ * sync_switchwhiten.py:206-215: P <- 1.5 P - 0.5 P^3 (S/tr S), wm = P sqrt(1/tr S)), and its backward (recomputes the
+ * chain; dcov from dwm).  cov, wm, dwm, dcov: fp32 [n,16,16]. */
+int mrfp_group_isqrt_fwd(const float* cov, float* wm, int64_t n, int T, void* stream);
+int mrfp_group_isqrt_bwd(const float* cov, const float* dwm, float* dcov, int64_t n, int T, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fourier amplitude perturbation (north_star extension; no function of this kind exists in the

@@ -163,6 +163,117 @@ __global__ __launch_bounds__(kThreads) void group_apply_kernel(const T* __restri
     }
 }
 
+// ---- inverse square root of the 16x16 group covariances: Newton-Schulz (reference sync_switchwhiten.py:206-215) ----
+//   r = 1/tr(S); Sn = S r; P_0 = I; P_{k+1} = 1.5 P_k - 0.5 P_k^3 Sn; wm = P_T sqrt(r)
+// One workgroup of 256 threads per matrix, thread (i,j) owns one element, operands in LDS (16 FMAs per product and
+// thread).  The backward kernel recomputes the P_k chain (T <= 8 copies in LDS) and walks it in reverse:
+//   dQ = -0.5 dP_{k+1};  dP_k = 1.5 dP_{k+1} + dQ (P^2 Sn)^T + P^T dQ (P Sn)^T + (P^2)^T dQ Sn^T;  dSn += (P^3)^T dQ
+//   dS = dSn r + dtr I,  dtr = -r^2 (sum(dwm . P_T) / (2 sqrt r) + sum(dSn . S))
+constexpr int kNsMaxT = 8;
+
+__device__ __forceinline__ float mm16(const float* A, const float* B, int i, int j) {        // (A B)[i][j]
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r = fmaf(A[i * 17 + k], B[k * 17 + j], r);
+    return r;
+}
+__device__ __forceinline__ float mm16_tn(const float* A, const float* B, int i, int j) {     // (A^T B)[i][j]
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r = fmaf(A[k * 17 + i], B[k * 17 + j], r);
+    return r;
+}
+__device__ __forceinline__ float mm16_nt(const float* A, const float* B, int i, int j) {     // (A B^T)[i][j]
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r = fmaf(A[i * 17 + k], B[j * 17 + k], r);
+    return r;
+}
+__device__ __forceinline__ float block_sum256(float v, float* red) {     // sum over the 256 threads; red: 4 floats
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void group_isqrt_fwd_kernel(const float* __restrict__ cov, float* __restrict__ wm, int T) {
+    __shared__ float Sn[16 * 17], P[16 * 17], A[16 * 17], Bm[16 * 17], red[4];
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15, e = i * 17 + j;
+    const size_t off = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float s = cov[off];
+    const float r = 1.f / block_sum256(i == j ? s : 0.f, red);
+    Sn[e] = s * r;
+    float p = i == j ? 1.f : 0.f;
+    P[e] = p;
+    __syncthreads();
+    for (int k = 0; k < T; ++k) {
+        A[e] = mm16(P, P, i, j);            // P^2
+        __syncthreads();
+        Bm[e] = mm16(A, P, i, j);           // P^3
+        __syncthreads();
+        p = 1.5f * p - 0.5f * mm16(Bm, Sn, i, j);
+        __syncthreads();
+        P[e] = p;
+        __syncthreads();
+    }
+    wm[off] = p * sqrtf(r);
+}
+
+__global__ __launch_bounds__(256) void group_isqrt_bwd_kernel(const float* __restrict__ cov, const float* __restrict__ dwm,
+                                                               float* __restrict__ dcov, int T) {
+    __shared__ float Sn[16 * 17], Pk[kNsMaxT + 1][16 * 17], A[16 * 17], Bm[16 * 17], Cm[16 * 17], G[16 * 17], dQ[16 * 17], red[4];
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15, e = i * 17 + j;
+    const size_t off = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float s = cov[off];
+    const float r = 1.f / block_sum256(i == j ? s : 0.f, red);
+    Sn[e] = s * r;
+    float p = i == j ? 1.f : 0.f;
+    Pk[0][e] = p;
+    __syncthreads();
+    for (int k = 0; k < T; ++k) {
+        A[e] = mm16(Pk[k], Pk[k], i, j);
+        __syncthreads();
+        Bm[e] = mm16(A, Pk[k], i, j);
+        __syncthreads();
+        p = 1.5f * p - 0.5f * mm16(Bm, Sn, i, j);
+        Pk[k + 1][e] = p;
+        __syncthreads();
+    }
+    const float sr = sqrtf(r);
+    const float g0 = dwm[off];
+    const float dr_a = block_sum256(g0 * p, red) * 0.5f / sr;      // wm = P_T sqrt(r)
+    float g = g0 * sr;                                             // dP_T
+    float dsn = 0.f;
+    for (int k = T - 1; k >= 0; --k) {
+        const float* Pc = Pk[k];
+        __syncthreads();
+        dQ[e] = -0.5f * g;
+        A[e] = mm16(Pc, Pc, i, j);            // P^2
+        Cm[e] = mm16(Pc, Sn, i, j);           // P Sn
+        __syncthreads();
+        Bm[e] = mm16(A, Sn, i, j);            // P^2 Sn
+        __syncthreads();
+        const float t1 = mm16_nt(dQ, Bm, i, j);                     // dQ (P^2 Sn)^T
+        const float u = mm16_tn(Pc, dQ, i, j);                      // P^T dQ
+        const float w = mm16_tn(A, dQ, i, j);                       // (P^2)^T dQ
+        __syncthreads();
+        Bm[e] = mm16(A, Pc, i, j);            // P^3
+        G[e] = u;
+        __syncthreads();
+        const float t2 = mm16_nt(G, Cm, i, j);                      // (P^T dQ) (P Sn)^T
+        dsn += mm16_tn(Bm, dQ, i, j);                               // (P^3)^T dQ
+        __syncthreads();
+        G[e] = w;
+        __syncthreads();
+        const float t3 = mm16_nt(G, Sn, i, j);                      // ((P^2)^T dQ) Sn^T
+        g = 1.5f * g + t1 + t2 + t3;
+    }
+    const float dr = dr_a + block_sum256(dsn * s, red);
+    const float dtr = -dr * r * r;
+    dcov[off] = dsn * r + (i == j ? dtr : 0.f);
+}
+
 static bool whiten_shape_ok(int64_t B, int64_t HW, int64_t C) {
     return B > 0 && B < 65536 && HW > 0 && HW < (1ll << 31) && C >= kG && C <= 1024 && C % kG == 0;
 }
@@ -232,6 +343,20 @@ int mrfp_group_apply(const void* x, const float* Wm, const void* z, const float*
     if (dtype == MRFP_BF16) return run_apply<bf16>(x, Wm, z, Vm, shift, y, B, HW, C, st);
     if (dtype == MRFP_F16) return run_apply<f16>(x, Wm, z, Vm, shift, y, B, HW, C, st);
     MRFP_CHECK(false, "group_apply: unknown dtype %d", dtype);
+}
+
+int mrfp_group_isqrt_fwd(const float* cov, float* wm, int64_t n, int T, void* stream) {
+    MRFP_CHECK(cov && wm && n > 0 && n < (1ll << 31) && T >= 0 && T <= kNsMaxT, "group_isqrt_fwd: bad arguments (T <= %d)", kNsMaxT);
+    hipLaunchKernelGGL(group_isqrt_fwd_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, cov, wm, T);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_group_isqrt_bwd(const float* cov, const float* dwm, float* dcov, int64_t n, int T, void* stream) {
+    MRFP_CHECK(cov && dwm && dcov && n > 0 && n < (1ll << 31) && T >= 0 && T <= kNsMaxT, "group_isqrt_bwd: bad arguments (T <= %d)", kNsMaxT);
+    hipLaunchKernelGGL(group_isqrt_bwd_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, cov, dwm, dcov, T);
+    MRFP_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // extern "C"

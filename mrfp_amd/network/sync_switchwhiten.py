@@ -156,12 +156,15 @@ class SyncSwitchWhiten2d(nn.Module):
             raise NotImplementedError("sw_type 4 is accepted by the reference constructor but has no forward branch")
 
         # Newton-Schulz inverse square root (reference sync_switchwhiten.py:206-215)
-        rTr = 1.0 / torch.diagonal(cov, dim1=-2, dim2=-1).sum(-1).view(N, g, 1, 1)
-        cov_n = cov * rTr
-        P = eye.expand(N, g, c, c)
-        for _ in range(self.T):
-            P = 1.5 * P - 0.5 * (P @ P @ P) @ cov_n
-        wm = P * rTr.sqrt()                                       # cov^{-1/2}, [N, g, c, c]
+        if c == 16 and self.use_group_kernels and self.T <= 8 and cov.is_cuda:
+            wm = ops.group_isqrt(cov, self.T)                     # one launch forward, one backward (csrc/whiten.hip)
+        else:
+            rTr = 1.0 / torch.diagonal(cov, dim1=-2, dim2=-1).sum(-1).view(N, g, 1, 1)
+            cov_n = cov * rTr
+            P = eye.expand(N, g, c, c)
+            for _ in range(self.T):
+                P = 1.5 * P - 0.5 * (P @ P @ P) @ cov_n
+            wm = P * rTr.sqrt()                                   # cov^{-1/2}, [N, g, c, c]
 
         # fold mean and affine into one per-image block-diagonal matrix + offset
         if self.affine:

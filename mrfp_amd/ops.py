@@ -889,6 +889,34 @@ def group_apply(x, Wm, shift):
     return _GroupApply.apply(x, Wm, shift)
 
 
+class _GroupISqrt(torch.autograd.Function):
+    """cov^{-1/2} of [..., 16, 16] covariance matrices by T Newton-Schulz steps (reference sync_switchwhiten.py:206-215),
+    forward and backward as one launch each (the backward recomputes the iteration)."""
+
+    @staticmethod
+    def forward(ctx, cov, T):
+        c = cov.detach().float().contiguous()
+        if c.shape[-1] != 16 or c.shape[-2] != 16 or not c.is_cuda:
+            raise _lib.MrfpHipError("group_isqrt: [...,16,16] matrices on the GPU expected, got %s" % (tuple(cov.shape),))
+        wm = torch.empty_like(c)
+        call("mrfp_group_isqrt_fwd", ptr(c), ptr(wm), c.numel() // 256, int(T), stream())
+        ctx.save_for_backward(c)
+        ctx.T = int(T)
+        return wm
+
+    @staticmethod
+    def backward(ctx, dwm):
+        (c,) = ctx.saved_tensors
+        g = dwm.float().contiguous()
+        dcov = torch.empty_like(c)
+        call("mrfp_group_isqrt_bwd", ptr(c), ptr(g), ptr(dcov), c.numel() // 256, ctx.T, stream())
+        return dcov, None
+
+
+def group_isqrt(cov, T=5):
+    return _GroupISqrt.apply(cov, T)
+
+
 class _GroupWhiten(torch.autograd.Function):
     """moments -> (small algebra, torch autograd) -> apply as ONE node, so that the backward pass touches the activation
     only twice: cross moments of (dy, x), then dx = Wm^T dy + (dM + dM^T) x + ds in a single pass."""

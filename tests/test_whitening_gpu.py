@@ -141,3 +141,25 @@ def test_switch_whiten_group_kernels_match_generic_passes(sw_type, tie):
         outs.append((y, x.grad, sw.weight.grad, sw.bias.grad, sw.sw_mean_weight.grad, sw.running_mean.clone(), sw.running_cov.clone()))
     for a, b in zip(*outs):
         assert relerr(a, b) < 5e-4
+
+
+def test_group_isqrt_matches_newton_schulz_autograd():
+    """mrfp_group_isqrt_{fwd,bwd} against the reference's Newton-Schulz loop differentiated by torch autograd."""
+    from mrfp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(37, 16, 48, generator=g)
+    cov0 = (a @ a.transpose(-1, -2) / 48 + 1e-3 * torch.eye(16)).to(DEV)
+    gw = torch.randn(37, 16, 16, generator=g).to(DEV)
+    for T in (1, 5, 8):
+        cr = cov0.clone().requires_grad_(True)
+        rTr = 1.0 / torch.diagonal(cr, dim1=-2, dim2=-1).sum(-1).view(-1, 1, 1)
+        cn = cr * rTr
+        P = torch.eye(16, device=DEV).expand(37, 16, 16)
+        for _ in range(T):
+            P = 1.5 * P - 0.5 * (P @ P @ P) @ cn
+        ref = P * rTr.sqrt()
+        (ref * gw).sum().backward()
+        cd = cov0.clone().requires_grad_(True)
+        out = ops.group_isqrt(cd, T)
+        (out * gw).sum().backward()
+        assert relerr(out, ref) < 2e-5 and relerr(cd.grad, cr.grad) < 2e-4
