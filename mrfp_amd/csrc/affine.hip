@@ -43,8 +43,9 @@ __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restric
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (xl) xr[u] = load_raw<T, VEC>(xl + (size_t)iwv[u] * g.C);
-                    if (res) rr[u] = load_raw<T, VEC>(res + dl + (size_t)owc[u] * g.C);
+                    if (xl) xr[u] = RESIZE ? load_raw<T, VEC>(xl + (size_t)iwv[u] * g.C)       // gathered: pixels repeat
+                                           : load_raw_nt<T, VEC>(xl + (size_t)iwv[u] * g.C);
+                    if (res) rr[u] = load_raw_nt<T, VEC>(res + dl + (size_t)owc[u] * g.C);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {      // unconditional, clamped (see stats.hip)
                         const int iw = min(iw0 + u * L.rowthreads, g.Ws - 1);
-                        dr[u] = load_raw<T, VEC>(dy + sl + (size_t)iw * g.C);
-                        if (x && (Q || remask)) xr[u] = load_raw<T, VEC>(x + sl + (size_t)iw * g.C);
-                        if (y) yr[u] = load_raw<T, VEC>(y + sl + (size_t)iw * g.C);
+                        dr[u] = load_raw_nt<T, VEC>(dy + sl + (size_t)iw * g.C);
+                        if (x && (Q || remask)) xr[u] = load_raw_nt<T, VEC>(x + sl + (size_t)iw * g.C);
+                        if (y) yr[u] = load_raw_nt<T, VEC>(y + sl + (size_t)iw * g.C);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {

@@ -65,6 +65,24 @@ __device__ __forceinline__ void store_f(T* p, const float (&in)[VEC]) {
 // raw (unconverted) vector loads: keep several 16-byte loads in flight per lane at 4 VGPRs each, convert on use
 template <typename T, int VEC>
 __device__ __forceinline__ VecT<T, VEC> load_raw(const T* p) { return *reinterpret_cast<const VecT<T, VEC>*>(p); }
+// the same with the non-temporal cache policy: for the LAST read of a tensor in a pass sequence (nothing re-reads these
+// bytes soon, so they should not displace lines that the next kernel will hit in L2 / the Infinity Cache).  Used by the
+// normalisation apply kernels (affine.hip; the statistics pass in front of them keeps the default policy so that the
+// apply pass finds the tensor in the caches): bench step 62.4 -> 61.4 ms (tools/ab_lib.sh, same box, 3 alternations;
+// `tools/build_variant.sh nont affine -DMRFP_NT=0` builds the default-policy library).
+#ifndef MRFP_NT
+#define MRFP_NT 1
+#endif
+template <typename T, int VEC>
+__device__ __forceinline__ VecT<T, VEC> load_raw_nt(const T* p) {
+    if constexpr (MRFP_NT != 0 && sizeof(T) * VEC == 16) {
+        typedef unsigned __attribute__((ext_vector_type(4))) nt_u32x4;
+        const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
+        return __builtin_bit_cast(VecT<T, VEC>, v);
+    } else {
+        return *reinterpret_cast<const VecT<T, VEC>*>(p);
+    }
+}
 template <typename T, int VEC>
 __device__ __forceinline__ void cvt_f(const VecT<T, VEC>& t, float (&out)[VEC]) {
 #pragma unroll
