@@ -79,6 +79,15 @@ template <> struct Mma<float> {
 #define MRFP_M16 1
 #endif
 constexpr bool kM16 = MRFP_M16 != 0;
+// MRFP_WIDE_EP (build switch, default on): tiles with several waves across N (WN > 1) stage a 32-row block of the WHOLE
+// workgroup tile in LDS and write full output rows (WN x wider runs, e.g. 256 instead of 64 bytes for the 96x128 tile)
+// instead of every wave writing its own 32*TN-column strip.  Small but consistent: bench step 61.8 -> 61.55 ms over three
+// alternations on one box (tools/ab_wide.sh) -- L2 write combining already hid most of the narrow runs; the short-K 1x1
+// layers stay bound by the fill -> multiply serialisation of their 4-step K loops, not by their stores.
+#ifndef MRFP_WIDE_EP
+#define MRFP_WIDE_EP 1
+#endif
+constexpr bool kWideEp = MRFP_WIDE_EP != 0;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <typename T> struct Mma16 {
     static __device__ __forceinline__ void run(f32x4&, const uint4&, const uint4&) {}
@@ -396,10 +405,14 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
     // chunks of output rows, 8 (bf16) / 4 (fp32) rows per wave-instruction, fully coalesced.
     constexpr int EPC = 16 / (int)sizeof(T);              // elements per 16-byte chunk
     constexpr int ROWB = 32 * TN * (int)sizeof(T);        // bytes of one row of the wave's tile
-    constexpr int EPITCH = ROWB + 16;                      // +16: the two lane halves (rows r, r+4) hit disjoint banks
-    constexpr int CPRW = ROWB / 16;                        // chunks per row (8 / 16)
-    constexpr int RPI = 64 / CPRW;                         // rows per wave-instruction (8 / 4)
-    char* const ep = smem + wave * (32 * EPITCH);          // 4.5 KB (bf16) / 8.5 KB (fp32) per wave
+    constexpr bool WIDE = kWideEp && WN > 1 && (64 % (WN * ROWB / 16) == 0) && (32 % WN == 0) &&
+                          ((32 / WN) % (64 / (WN * ROWB / 16)) == 0);
+    constexpr int EPITCH = (WIDE ? WN * ROWB : ROWB) + 16; // +16: the two lane halves (rows r, r+4) hit disjoint banks
+    constexpr int CPRW = (WIDE ? WN * ROWB : ROWB) / 16;   // chunks per staged row
+    constexpr int RPI = 64 / CPRW;                         // rows per wave-instruction
+    // per-wave strips: 4.5 KB (bf16) / 8.5 KB (fp32) per wave; WIDE: one 32-row block of the workgroup tile per wave row
+    char* const ep = WIDE ? smem + wm * (32 * EPITCH) + wn * ROWB : smem + wave * (32 * EPITCH);
+    char* const epr = WIDE ? smem + wm * (32 * EPITCH) : ep;
     T* y = reinterpret_cast<T*>(p.y);
     const int nb = n0 + wn * 32 * TN;
     float bv[2 * TN], cs[2 * TN], cq[2 * TN];      // 32x32 blocks use the first TN entries, 16x16 blocks all of them
@@ -443,14 +456,17 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
                 }
             }
         // same-wave LDS round trip: no workgroup barrier needed, only the wave's own LDS ops must have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // also a compiler barrier (T stores vs uint4 loads)
+        // (WIDE: the block is shared by the WN waves of this wave row -> workgroup barriers around the read-out)
+        if constexpr (WIDE) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // also a compiler barrier (T stores vs uint4 loads)
         const int mb = m0 + wm * 32 * TM + i * 32;
+        constexpr int NK = WIDE ? (32 / WN) / RPI : 32 / RPI;      // read-out instructions of this wave
 #pragma unroll
-        for (int k = 0; k < 32 / RPI; ++k) {
-            const int row = k * RPI + lane / CPRW, ch = lane % CPRW;
-            const int m = mb + row, n = nb + ch * EPC;
+        for (int k = 0; k < NK; ++k) {
+            const int row = (WIDE ? wn * (32 / WN) : 0) + k * RPI + lane / CPRW, ch = lane % CPRW;
+            const int m = mb + row, n = (WIDE ? n0 : nb) + ch * EPC;
             if (m < p.M && n < p.N) {
-                uint4 v = *reinterpret_cast<const uint4*>(ep + row * EPITCH + ch * 16);
+                uint4 v = *reinterpret_cast<const uint4*>(epr + row * EPITCH + ch * 16);
                 T* dst = y + (size_t)m * p.ldy + n;
                 const bool full = n + EPC <= p.N;
                 // (everything below indexes the chunk with compile-time constants only: a run-time index would
@@ -476,7 +492,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (WIDE) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (p.colstats) {
         // a lane holds 16 of the 32 rows of each block column, its partner (lane ^ 32) the other 16
