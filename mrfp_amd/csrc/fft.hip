@@ -294,6 +294,12 @@ static int fft_nopair() {        // MRFP_FFT_NOPAIR=1: band-limited row passes o
     return v;
 }
 
+static int fft_nodirect() {      // MRFP_FFT_NODIRECT=1: band-limited inverse row pass on the register FFT (A/B)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRFP_FFT_NODIRECT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 // workgroup id -> (line, channel group): the channel groups of one line are consecutive on one XCD
 __device__ __forceinline__ bool decode_wg(int nlines, int ncg, int& line, int& cg) {
     const int wg = blockIdx.x, xcd = wg & 7, i = wg >> 3;
@@ -473,6 +479,101 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_rows_inv_pair_kernel(FftP 
     }
 }
 
+// ---- band-limited inverse row pass as a DIRECT trigonometric sum ---------------------------------------------------
+// With only Ws stored bins a line is  y[w] = x[w] + sum_k g_k (Re D_k cos th_kw - Im D_k sin th_kw),  th_kw = 2 pi k w / W,
+// g_0 = 1, g_k = 2 (Hermitian mirror), scale folded in.  The four positions j, W/2-j, W/2+j, W-j (j <= W/4) share
+// |cos| and |sin| up to the signs (-1)^k and +-1, so one pass over the Ws bins -- 2 packed FMAs per bin for a channel
+// pair, into (P_even, P_odd, Q_even, Q_odd) -- yields four outputs:
+//   y[j] = (Pe+Po) - (Qe+Qo)   y[W-j] = (Pe+Po) + (Qe+Qo)   y[W/2+j] = (Pe-Po) - (Qe-Qo)   y[W/2-j] = (Pe-Po) + (Qe-Qo)
+// ~4x fewer instructions than the register FFT of the same line (which transforms W points of which 2 Ws - 1 are
+// non-zero).  A thread is (channel pair < 32, slot < 8): 64 channels per workgroup (128-byte bf16 runs), j = slot + 8 i.
+// A thread is (channel group, slot): PPT channel pairs per thread (16-byte activation accesses: 4 pairs for the 16-bit
+// types, 2 for fp32 -- with one pair per thread the bf16 pass took as long as the fp32 one, i.e. it was bound by the number
+// of memory instructions, not by bytes), 64 channels per workgroup, j = slot + NSLOT i.
+constexpr int kDirCh = 64, kDirThreads = 256;
+static int dir_lines() {         // lines per workgroup of the direct pass (the trig table is built once per workgroup)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRFP_FFT_DIRLINES"); v = e ? atoi(e) : 1; if (v < 1) v = 1; }
+    return v;
+}
+template <typename T, int PPT, int CH>
+__global__ __launch_bounds__(kDirThreads) void dft_rows_inv_direct_kernel(FftP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TC = CH / (2 * PPT), NSLOT = kDirThreads / TC, NP = CH / 2;
+    const int Ws = p.Ws, W = p.W, NJ = W / 4 + 1;
+    float4* stage = reinterpret_cast<float4*>(smem);                         // [Ws][32 pairs]: (Re, Im) of both channels
+    float2* trig = reinterpret_cast<float2*>(stage + Ws * NP);               // [NJ][Ws]: g_k scale (cos, sin)(2 pi k j / W)
+    const int tc = threadIdx.x % TC, slot = threadIdx.x / TC;
+    int lgrp, cg;
+    const int nlines = p.B * p.H;
+    const int LPW = p.N;                                                     // lines per workgroup
+    if (!decode_wg((nlines + LPW - 1) / LPW, p.C / CH, lgrp, cg)) return;
+    const size_t C = p.C;
+    for (int i = threadIdx.x; i < NJ * Ws; i += kDirThreads) {                // once per workgroup (LPW lines)
+        const int j = i / Ws, k = i - j * Ws;
+        const float2 t = p.tw[(k * j) % W];                                 // exp(-2 pi i k j / W) = (cos, -sin)
+        const float g = (k == 0 ? 1.f : 2.f) * p.scale;
+        trig[i] = make_float2(g * t.x, -g * t.y);
+    }
+    for (int li = 0; li < LPW; ++li) {
+    const int line = lgrp * LPW + li;
+    if (line >= nlines) break;                                               // workgroup-uniform
+    __syncthreads();                                                         // the previous line's reads of `stage` are done
+    {
+        const float* src = reinterpret_cast<const float*>(p.S3 + (size_t)line * Ws * C + cg * CH);
+        for (int i = threadIdx.x; i < Ws * NP; i += kDirThreads) {
+            const int k = i / NP, pr = i - k * NP;
+            stage[i] = *reinterpret_cast<const float4*>(src + ((size_t)k * C + 2 * pr) * 2);
+        }
+    }
+    __syncthreads();
+    const size_t cofs = (size_t)line * W * C + cg * CH + 2 * PPT * tc;
+    const T* xs = reinterpret_cast<const T*>(p.x) + cofs;
+    T* dst = reinterpret_cast<T*>(p.y) + cofs;
+    for (int j = slot; j < NJ; j += NSLOT) {
+        const int w0 = j, w1 = W / 2 - j, w2 = W / 2 + j, w3 = j == 0 ? 0 : W - j;
+        float x0[2 * PPT], x1[2 * PPT], x2[2 * PPT], x3[2 * PPT];
+        load_f<T, 2 * PPT>(xs + (size_t)w0 * C, x0);
+        load_f<T, 2 * PPT>(xs + (size_t)w1 * C, x1);
+        load_f<T, 2 * PPT>(xs + (size_t)w2 * C, x2);
+        load_f<T, 2 * PPT>(xs + (size_t)w3 * C, x3);
+        float Pe[2 * PPT], Po[2 * PPT], Qe[2 * PPT], Qo[2 * PPT];
+#pragma unroll
+        for (int u = 0; u < 2 * PPT; ++u) { Pe[u] = 0.f; Po[u] = 0.f; Qe[u] = 0.f; Qo[u] = 0.f; }
+        const float2* tj = trig + j * Ws;
+        const float4* sg = stage + PPT * tc;
+        for (int k = 0; k < Ws; k += 2) {
+            const float2 t0 = tj[k];
+            const bool odd = k + 1 < Ws;
+            const float2 t1 = odd ? tj[k + 1] : make_float2(0.f, 0.f);
+            const int k1 = odd ? k + 1 : k;
+#pragma unroll
+            for (int u = 0; u < PPT; ++u) {
+                const float4 d0 = sg[k * NP + u], d1 = sg[k1 * NP + u];
+                Pe[2 * u] = fmaf(d0.x, t0.x, Pe[2 * u]); Pe[2 * u + 1] = fmaf(d0.z, t0.x, Pe[2 * u + 1]);
+                Qe[2 * u] = fmaf(d0.y, t0.y, Qe[2 * u]); Qe[2 * u + 1] = fmaf(d0.w, t0.y, Qe[2 * u + 1]);
+                Po[2 * u] = fmaf(d1.x, t1.x, Po[2 * u]); Po[2 * u + 1] = fmaf(d1.z, t1.x, Po[2 * u + 1]);
+                Qo[2 * u] = fmaf(d1.y, t1.y, Qo[2 * u]); Qo[2 * u + 1] = fmaf(d1.w, t1.y, Qo[2 * u + 1]);
+            }
+        }
+        float o0[2 * PPT], o1[2 * PPT], o2[2 * PPT], o3[2 * PPT];
+#pragma unroll
+        for (int u = 0; u < 2 * PPT; ++u) {
+            const float Ps = Pe[u] + Po[u], Pd = Pe[u] - Po[u], Qs = Qe[u] + Qo[u], Qd = Qe[u] - Qo[u];
+            o0[u] = x0[u] + (Ps - Qs);
+            o3[u] = x3[u] + (Ps + Qs);
+            o2[u] = x2[u] + (Pd - Qd);
+            o1[u] = x1[u] + (Pd + Qd);
+        }
+        const bool inner = j != 0 && 4 * j != W;          // j = 0 and j = W/4: the mirrored positions coincide
+        store_f<T, 2 * PPT>(dst + (size_t)w0 * C, o0);
+        if (inner || j == 0) store_f<T, 2 * PPT>(dst + (size_t)w2 * C, o2);
+        if (inner || 4 * j == W) store_f<T, 2 * PPT>(dst + (size_t)w3 * C, o3);
+        if (inner) store_f<T, 2 * PPT>(dst + (size_t)w1 * C, o1);
+    }
+    }
+}
+
 template <int N1, int N2>
 __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -563,6 +664,21 @@ static int launch_fast_pass(FftP p, int pass, const float2* tw, hipStream_t st) 
     using TS = TwoStep<N1, N2>;
     p.N = TS::N;
     p.tw = tw;
+    if (p.delta && pass == 2 && p.C % kDirCh == 0 && p.Ws <= 64 && !fft_nopair() && !fft_nodirect()) {
+        // band-limited inverse row pass as a direct trigonometric sum
+        constexpr int PPT = 8 / (int)sizeof(T);            // 16-byte activation accesses
+        p.N = dir_lines();
+        const int ngrp = (p.B * p.H + p.N - 1) / p.N;
+        // (a 128-channel tile -- 256-byte bf16 runs -- measured 7 % slower; 2..8 lines per workgroup the same as 1)
+        const unsigned grid = (unsigned)(((ngrp + 7) / 8) * 8 * (p.C / kDirCh));
+        const int lds = p.Ws * (kDirCh / 2) * (int)sizeof(float4) + (p.W / 4 + 1) * p.Ws * (int)sizeof(float2);
+        auto kern = &dft_rows_inv_direct_kernel<T, PPT, kDirCh>;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kDirThreads), lds, st, p);
+        MRFP_LAUNCH_CHECK();
+        return 0;
+    }
     if (p.delta && p.C % (2 * kCB) == 0 && pass != 1 && !fft_nopair()) {     // band-limited row passes on channel pairs
         const FftP& q = p;
         const unsigned grid = (unsigned)(((p.B * p.H + 7) / 8) * 8 * (p.C / (2 * kCB)));

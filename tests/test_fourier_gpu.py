@@ -25,7 +25,10 @@ def relerr(a, b):
                                                    # band-limited low-band path (floor(radius)+1 stored columns): one bin,
                                                    # fractional radius, a radius past the last column (full spectrum)
                                                    ((2, 16, 64, 64), 0.0, 1.0, False), ((3, 32, 64, 128), 3.5, 0.8, False),
-                                                   ((2, 16, 32, 48), 30.0, 1.0, False), ((2, 48, 128, 96), 24.0, 1.0, False)])
+                                                   ((2, 16, 32, 48), 30.0, 1.0, False), ((2, 48, 128, 96), 24.0, 1.0, False),
+                                                   # 64-channel tiles: inverse row pass as a direct trigonometric sum
+                                                   ((2, 64, 96, 192), 16.0, 1.0, False), ((2, 128, 64, 128), 5.5, 0.7, False),
+                                                   ((1, 64, 32, 48), 3.0, 1.0, False), ((2, 64, 48, 32), 0.0, 1.0, False)])
 def test_fourier_amplitude_mix(dtype, shape, radius, lam, high):
     from mrfp_amd import ops
     B, C, H, W = shape
