@@ -33,6 +33,23 @@ def test_host_only_entry_points(cdll):
     assert rc != 0 and b"add" in cdll.mrfp_last_error()
 
 
+def test_fourier_and_whitening_host_queries(cdll):
+    """Host-only queries of the Fourier / whitening families: the band-limited low-band path stores floor(radius)+1
+    spectrum columns on planned line lengths and the whole half spectrum otherwise; workspace sizes; argument checks."""
+    sb = cdll.mrfp_fourier_stored_bins
+    assert sb(192, 192, 16.0, 0) == 17 and sb(192, 192, 16.9, 0) == 17 and sb(192, 192, 0.0, 0) == 1
+    assert sb(192, 192, 16.0, 1) == 97                      # high band: the whole half spectrum
+    assert sb(192, 192, 500.0, 0) == 97 and sb(32, 48, 30.0, 0) == 25
+    assert sb(8, 8, 2.0, 0) == 5 and sb(12, 18, 3.0, 0) == 10   # no register plan for these lengths: generic path
+    assert cdll.mrfp_fourier_spectrum_bytes(2, 8, 8, 16) == 2 * 8 * 5 * 16 * 8
+    ws = cdll.mrfp_group_moments_ws_bytes
+    assert ws(16, 192 * 192, 256) > 0 and ws(16, 192 * 192, 256) % (64 * 68 * 4) == 0
+    assert ws(2, 100, 24) == 0 and ws(2, 100, 2048) == 0    # C % 16 != 0, C > 1024: unsupported
+    assert cdll.mrfp_group_moments(None, None, None, None, None, 0, 1, 1, 16, None) != 0
+    assert b"group_moments" in cdll.mrfp_last_error()
+    assert cdll.mrfp_group_isqrt_fwd(None, None, 1, 5, None) != 0 and b"group_isqrt" in cdll.mrfp_last_error()
+
+
 def test_nearest_tables_match_aten():
     """The host-side index tables the kernels consume == F.interpolate(mode='nearest')."""
     import numpy as np
