@@ -283,6 +283,25 @@ int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void*
                      const void* twH, const void* twW, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
                      float radius, float lam, int high, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Geometric part of the training input pipeline, bit-exact with the PIL calls of the reference (main.py:409-419
+ * transform_tr: dataloaders.py:139-150 flip, 398-435 RandomSizeAndCrop = img.resize(BICUBIC) / mask.resize(NEAREST),
+ * 257-337 RandomCrop with ImageOps.expand padding, 118-136 ToTensor).  Pillow resizes 8-bit images in two separable
+ * fixed-point passes: out = clip8((2^21 + sum_t in[lo + t] * coefs[o][t]) >> 22), horizontal first.
+ *   mrfp_resample_u8: one pass over a uint8 [Hin,Win,C] image; bounds [out][2] = (lo, count), coefs [out][ksize] int32
+ *     (host-built as Pillow builds them, mrfp_amd/input_pipeline.py); vertical = 0: Hout == Hin, flip != 0 reads the
+ *     source mirrored (the reference flips before it scales); vertical = 1: Wout == Win.
+ *   mrfp_input_assemble: pad (image 0 / label `ignore`) + crop + ToTensor.  img: scaled uint8 [Hs,Ws,3]; lab: ORIGINAL
+ *     uint8 label map [Hl,Wl]; ytab [Hs], xtab [Ws]: Pillow's nearest-neighbour source indices of the scaled label;
+ *     the scaled image sits at (pad_x, pad_y) of the padded one, the crop starts at (x1, y1); out_img float [3,Hc,Wc]
+ *     (values 0..255, no /255, as dataloaders.py:128-133), out_lab int64 [Hc,Wc].
+ * ------------------------------------------------------------------------------------------- */
+int mrfp_resample_u8(const void* src, void* dst, int64_t Hin, int64_t Win, int64_t Hout, int64_t Wout, int64_t C,
+                     const int32_t* bounds, const int32_t* coefs, int ksize, int vertical, int flip, void* stream);
+int mrfp_input_assemble(const void* img, const void* lab, const int32_t* ytab, const int32_t* xtab, int64_t Hs, int64_t Ws,
+                        int64_t Hl, int64_t Wl, int flip, int pad_x, int pad_y, int x1, int y1, int64_t Hc, int64_t Wc, int ignore,
+                        float* out_img, int64_t* out_lab, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

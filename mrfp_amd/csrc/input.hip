@@ -1,0 +1,112 @@
+// input.hip -- geometric part of the training input pipeline on the GPU, bit-exact with the PIL calls the reference makes
+// (main.py:409-419 transform_tr; dataloaders.py:139-150 RandomHorizontalFlip, 398-435 RandomSizeAndCrop -> img.resize(BICUBIC)
+// / mask.resize(NEAREST), 257-337 RandomCrop with ImageOps.expand padding, 467-482 Resize, 118-136 ToTensor).
+//
+// PIL (Pillow 12.2, src/libImaging/Resample.c) resizes 8-bit images in two separable passes with fixed-point
+// coefficients: out = clip8((2^21 + sum_x in[xmin + x] * k[x]) >> 22), horizontal pass first, 8-bit intermediate.  The
+// coefficient / bounds tables are built on the host in double precision exactly as Pillow does (mrfp_amd/input_pipeline.py,
+// oracle/input_oracle.py); the kernels do the integer arithmetic, so the result equals PIL's byte for byte.
+//   resample_u8   one separable pass over a [H,W,C] uint8 image (the horizontal pass can read the source mirrored: the
+//                 reference flips BEFORE it scales)
+//   assemble      pad (ImageOps.expand: image 0, label ignore_index) + crop + ToTensor: float32 [3,Hc,Wc] in 0..255 and the
+//                 int64 label map, the label fetched through PIL's nearest-neighbour index tables from the ORIGINAL map
+#include "common.hpp"
+
+namespace mrfp {
+
+constexpr int kPrecisionBits = 32 - 8 - 2;      // Pillow Resample.c PRECISION_BITS
+
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int Hin,
+                                                          int Win, int Hout, int Wout, int C, const int32_t* __restrict__ bounds,
+                                                          const int32_t* __restrict__ coefs, int ksize, int vertical, int flip) {
+    const int64_t n = (int64_t)Hout * Wout * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int ox = (int)(pix % Wout), oy = (int)(pix / Wout);
+        const int o = vertical ? oy : ox;
+        const int lo = bounds[2 * o], cnt = bounds[2 * o + 1];
+        const int32_t* k = coefs + (int64_t)o * ksize;
+        int acc = 1 << (kPrecisionBits - 1);
+        if (vertical) {
+            for (int t = 0; t < cnt; ++t) acc += (int)src[((int64_t)(lo + t) * Win + ox) * C + c] * k[t];
+        } else {
+            for (int t = 0; t < cnt; ++t) {
+                const int sx = flip ? Win - 1 - (lo + t) : lo + t;
+                acc += (int)src[((int64_t)oy * Win + sx) * C + c] * k[t];
+            }
+        }
+        const int v = acc >> kPrecisionBits;                // arithmetic shift, then clip8
+        dst[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
+__global__ __launch_bounds__(256) void input_assemble_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ lab,
+                                                             const int32_t* __restrict__ ytab, const int32_t* __restrict__ xtab,
+                                                             int Hs, int Ws, int Hl, int Wl, int flip, int pad_x, int pad_y, int x1,
+                                                             int y1, int Hc, int Wc, int ignore, float* __restrict__ out_img,
+                                                             int64_t* __restrict__ out_lab) {
+    const int64_t n = (int64_t)Hc * Wc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wc), oy = (int)(i / Wc);
+        const int px = x1 + ox - pad_x, py = y1 + oy - pad_y;       // position in the scaled image
+        const bool inside = px >= 0 && px < Ws && py >= 0 && py < Hs;
+        float r = 0.f, g = 0.f, b = 0.f;
+        int64_t l = ignore;
+        if (inside) {
+            const uint8_t* p = img + ((int64_t)py * Ws + px) * 3;
+            r = (float)p[0]; g = (float)p[1]; b = (float)p[2];
+            const int sy = ytab[py], sx0 = xtab[px];
+            if (sy >= 0 && sy < Hl && sx0 >= 0 && sx0 < Wl) l = lab[(int64_t)sy * Wl + (flip ? Wl - 1 - sx0 : sx0)];
+            else l = 0;                                               // ImagingScaleAffine leaves such pixels of a new image zero
+        }
+        out_img[i] = r;
+        out_img[n + i] = g;
+        out_img[2 * n + i] = b;
+        out_lab[i] = l;
+    }
+}
+
+}  // namespace mrfp
+
+using namespace mrfp;
+
+extern "C" {
+
+int mrfp_resample_u8(const void* src, void* dst, int64_t Hin, int64_t Win, int64_t Hout, int64_t Wout, int64_t C,
+                     const int32_t* bounds, const int32_t* coefs, int ksize, int vertical, int flip, void* stream) {
+    MRFP_CHECK(src && dst && bounds && coefs && ksize > 0, "resample_u8: null argument");
+    MRFP_CHECK(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0 && Hin < 65536 && Win < 65536 && Hout < 65536 && Wout < 65536,
+               "resample_u8: bad sizes");
+    MRFP_CHECK(vertical ? Wout == Win : Hout == Hin, "resample_u8: a pass changes one axis only (%s pass: %lldx%lld -> %lldx%lld)",
+               vertical ? "vertical" : "horizontal", (long long)Hin, (long long)Win, (long long)Hout, (long long)Wout);
+    MRFP_CHECK(!(vertical && flip), "resample_u8: the mirrored read belongs to the horizontal pass");
+    const int64_t n = Hout * Wout * C;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(resample_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
+                       (uint8_t*)dst, (int)Hin, (int)Win, (int)Hout, (int)Wout, (int)C, bounds, coefs, ksize, vertical, flip);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_input_assemble(const void* img, const void* lab, const int32_t* ytab, const int32_t* xtab, int64_t Hs, int64_t Ws,
+                        int64_t Hl, int64_t Wl, int flip, int pad_x, int pad_y, int x1, int y1, int64_t Hc, int64_t Wc, int ignore,
+                        float* out_img, int64_t* out_lab, void* stream) {
+    MRFP_CHECK(img && lab && ytab && xtab && out_img && out_lab, "input_assemble: null argument");
+    MRFP_CHECK(Hs > 0 && Ws > 0 && Hl > 0 && Wl > 0 && Hc > 0 && Wc > 0 && Hs < 65536 && Ws < 65536 && Hc < 65536 && Wc < 65536,
+               "input_assemble: bad sizes");
+    MRFP_CHECK(pad_x >= 0 && pad_y >= 0 && x1 >= 0 && y1 >= 0 && x1 + Wc <= Ws + 2 * pad_x && y1 + Hc <= Hs + 2 * pad_y,
+               "input_assemble: the crop [%d,%d)+%lldx%lld leaves the padded image %lldx%lld", x1, y1, (long long)Wc, (long long)Hc,
+               (long long)(Ws + 2 * pad_x), (long long)(Hs + 2 * pad_y));
+    const int64_t n = Hc * Wc;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(input_assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img,
+                       (const uint8_t*)lab, ytab, xtab, (int)Hs, (int)Ws, (int)Hl, (int)Wl, flip, pad_x, pad_y, x1, y1, (int)Hc, (int)Wc,
+                       ignore, out_img, out_lab);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+"""Geometric part of the reference's training transform on the GPU, bit-exact with its PIL calls.
+
+Reference: main.py:409-419 `transform_tr` = RandomHorizontalFlip -> ColorJitter -> RandomSizeAndCrop(crop_size,
+crop_nopad=False, ignore_index=255) -> Resize(crop_size) -> RandomGaussianBlur -> ToTensor (dataloaders.py).  This module
+does flip, the BICUBIC / NEAREST rescale, the ImageOps.expand padding, the crop and ToTensor on the device: uint8 image
+and label map in, float32 [3,H,W] (0..255) and int64 [H,W] out, byte for byte what PIL produces (tests/test_input_gpu.py).
+NOT included: ColorJitter (dataloaders.py:596-660: PIL ImageEnhance blends + an HSV round trip) and RandomGaussianBlur
+(:168-177: PIL's box-blur approximation) -- `draw()` still consumes their gates from the random stream and reports them,
+so a caller can route those samples through the CPU transform; the Resize step is the identity here (the crop already has
+crop_size) and PIL returns a copy for it.
+
+The fixed-point coefficient tables of Pillow's resampler are built on the host exactly as Pillow builds them
+(src/libImaging/Resample.c, double precision) and cached per (source size, destination size); the kernels
+(csrc/input.hip) do the integer arithmetic."""
+from __future__ import annotations
+
+import math
+import random as _random
+from dataclasses import dataclass
+from functools import lru_cache
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic_vec(x: np.ndarray) -> np.ndarray:
+    a = -0.5
+    x = np.abs(x)
+    near = ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    far = (((x - 5) * x + 8) * x - 4) * a
+    return np.where(x < 1.0, near, np.where(x < 2.0, far, 0.0))
+
+
+@lru_cache(maxsize=256)
+def _bicubic_tables(in_size: int, out_size: int):
+    """Pillow precompute_coeffs(BICUBIC) + normalize_coeffs_8bpc -> (bounds int32 [out,2], coefs int32 [out,ksize]).
+    Vectorised over the destination index with the same IEEE double operations in the same order as Pillow's scalar loop
+    (the weight sum is a sequential cumsum, not numpy's pairwise sum); checked entry by entry against the scalar
+    restatement in oracle/input_oracle.py (tests/test_input_cpu.py)."""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    xx = np.arange(out_size, dtype=np.float64)
+    center = 0.0 + (xx + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)            # (int) truncates; the argument is > -1
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    t = np.arange(ksize, dtype=np.float64)[None, :]
+    live = np.arange(ksize)[None, :] < xmax[:, None]
+    w = np.where(live, _bicubic_vec((t + xmin[:, None] - center[:, None] + 0.5) * ss), 0.0)
+    ww = np.cumsum(w, axis=1)[:, -1:]                                           # sequential adds, trailing zeros change nothing
+    w = np.where(ww != 0.0, w / np.where(ww != 0.0, ww, 1.0), w)
+    one = float(1 << PRECISION_BITS)
+    coefs = np.where(w < 0, -0.5 + w * one, 0.5 + w * one).astype(np.int32)     # C (int) cast: truncation
+    coefs = np.where(live, coefs, 0).astype(np.int32)
+    bounds = np.stack([xmin, xmax], 1).astype(np.int32)
+    return bounds, np.ascontiguousarray(coefs)
+
+
+@lru_cache(maxsize=256)
+def _nearest_table(in_size: int, out_size: int) -> np.ndarray:
+    """ImagingScaleAffine: xo = a/2, xin = (int)xo, xo += a (accumulated in double: a sequential cumsum)."""
+    a = float(in_size) / out_size
+    steps = np.full(out_size, a, dtype=np.float64)
+    steps[0] = 0.0 + a * 0.5
+    xo = np.cumsum(steps)
+    return np.where(xo < 0.0, -1, xo.astype(np.int64)).astype(np.int32)
+
+
+@dataclass
+class Draw:
+    flip: bool
+    jitter: bool                       # ColorJitter gate (not applied on the GPU path)
+    scaled: Tuple[int, int]            # (w, h) after RandomSizeAndCrop's rescale
+    pad: Tuple[int, int]               # (pad_w, pad_h) of ImageOps.expand on every side
+    crop: Tuple[int, int]              # (x1, y1) in the padded image
+    blur: Optional[float]              # GaussianBlur radius when its gate fired (not applied on the GPU path)
+
+
+class TrainTransform:
+    """transform_tr of the reference (main.py:409-419) without ColorJitter / GaussianBlur, on the device."""
+
+    def __init__(self, crop_size: int, scale_min: float = 0.5, scale_max: float = 2.0, ignore_index: int = 255):
+        self.crop_size, self.scale_min, self.scale_max, self.ignore_index = int(crop_size), scale_min, scale_max, ignore_index
+        self._dev_tables = {}
+
+    def draw(self, w: int, h: int, rng=_random) -> Draw:
+        """Consumes python's `random` stream in the reference's order (dataloaders.py:145, 655, 421, 327-331, 172-174)."""
+        flip = rng.random() < 0.5
+        jitter = rng.random() < 0.5                       # its factors come from np.random, not from this stream
+        scale_amt = 1.0 * rng.uniform(self.scale_min, self.scale_max)
+        sw, sh = int(w * scale_amt), int(h * scale_amt)
+        t = self.crop_size
+        pad_w = pad_h = 0
+        x1 = y1 = 0
+        if not (sw == t and sh == t):
+            pad_h = (t - sh) // 2 + 1 if t > sh else 0
+            pad_w = (t - sw) // 2 + 1 if t > sw else 0
+            W2, H2 = sw + 2 * pad_w, sh + 2 * pad_h
+            x1 = 0 if W2 == t else rng.randint(0, W2 - t)
+            y1 = 0 if H2 == t else rng.randint(0, H2 - t)
+        blur = rng.random() if rng.random() < 0.5 else None
+        return Draw(flip, jitter, (sw, sh), (pad_w, pad_h), (x1, y1), blur)
+
+    def _tables(self, dev, H, W, sh, sw):
+        key = (str(dev), H, W, sh, sw)
+        t = self._dev_tables.get(key)
+        if t is None:
+            bx, kx = _bicubic_tables(W, sw)
+            by, ky = _bicubic_tables(H, sh)
+            t = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+                      (bx, kx, by, ky, _nearest_table(W, sw), _nearest_table(H, sh))) + (kx.shape[1], ky.shape[1])
+            if len(self._dev_tables) > 64:
+                self._dev_tables.clear()
+            self._dev_tables[key] = t
+        return t
+
+    def __call__(self, img_u8: torch.Tensor, lab_u8: torch.Tensor, d: Draw, out_img: Optional[torch.Tensor] = None,
+                 out_lab: Optional[torch.Tensor] = None):
+        """img_u8: uint8 [H,W,3], lab_u8: uint8 [H,W], both on the GPU -> (float32 [3,T,T], int64 [T,T])."""
+        if not (img_u8.is_cuda and lab_u8.is_cuda and img_u8.dtype == torch.uint8 and lab_u8.dtype == torch.uint8):
+            raise _lib.MrfpHipError("TrainTransform: uint8 CUDA tensors expected (there is no CPU path)")
+        H, W, C = img_u8.shape
+        if C != 3 or tuple(lab_u8.shape) != (H, W):
+            raise _lib.MrfpHipError("TrainTransform: image [H,W,3] and label [H,W] expected")
+        img_u8, lab_u8 = img_u8.contiguous(), lab_u8.contiguous()
+        dev, T = img_u8.device, self.crop_size
+        sw, sh = d.scaled
+        bx, kx, by, ky, tx, ty, ksx, ksy = self._tables(dev, H, W, sh, sw)
+        cur = img_u8
+        if sw != W or d.flip:       # horizontal pass first (Pillow ImagingResample), reading the source mirrored when flipped
+            # (at sw == W the coefficients are exactly (0, 1, 0): the pass is then a plain mirrored copy)
+            tmp = torch.empty((H, sw, 3), dtype=torch.uint8, device=dev)
+            call("mrfp_resample_u8", ptr(cur), ptr(tmp), H, W, H, sw, 3, ptr(bx), ptr(kx), ksx, 0, int(d.flip), stream())
+            cur = tmp
+        if sh != H:
+            tmp = torch.empty((sh, sw, 3), dtype=torch.uint8, device=dev)
+            call("mrfp_resample_u8", ptr(cur), ptr(tmp), H, sw, sh, sw, 3, ptr(by), ptr(ky), ksy, 1, 0, stream())
+            cur = tmp
+        if out_img is None:
+            out_img = torch.empty((3, T, T), dtype=torch.float32, device=dev)
+        if out_lab is None:
+            out_lab = torch.empty((T, T), dtype=torch.int64, device=dev)
+        call("mrfp_input_assemble", ptr(cur), ptr(lab_u8), ptr(ty), ptr(tx), sh, sw, H, W, int(d.flip), d.pad[0], d.pad[1],
+             d.crop[0], d.crop[1], T, T, int(self.ignore_index), ptr(out_img), ptr(out_lab), stream())
+        return out_img, out_lab

@@ -1,0 +1,43 @@
+"""Input pipeline on the GPU (csrc/input.hip, mrfp_amd/input_pipeline.py) against the reference's PIL calls
+(oracle/input_oracle.py::transform_pil): byte-exact image and label for flipped / unflipped, up- and down-scaled,
+padded and unpadded draws."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import input_oracle as io
+
+pytestmark = pytest.mark.gpu
+Image = pytest.importorskip("PIL.Image")
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("H,W,crop", [(96, 128, 64), (60, 90, 96), (128, 256, 128), (75, 75, 75)])
+def test_train_transform_equals_pil(H, W, crop):
+    from mrfp_amd.input_pipeline import Draw, TrainTransform
+    rng = np.random.default_rng(H + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    lab = rng.integers(0, 19, (H, W), dtype=np.uint8)
+    lab[rng.random((H, W)) < 0.03] = 255
+    tt = TrainTransform(crop, 0.5, 2.0, 255)
+    r = random.Random(7)
+    draws = [tt.draw(W, H, r) for _ in range(10)]
+    draws.append(Draw(True, False, (W, H), ((crop - W) // 2 + 1 if crop > W else 0, (crop - H) // 2 + 1 if crop > H else 0),
+                      (0, 0), None))                                  # scale exactly 1: mirrored copy only
+    xi, xl = torch.from_numpy(img).to(DEV), torch.from_numpy(lab).to(DEV)
+    for d in draws:
+        want_im, want_lab = io.transform_pil(Image.fromarray(img), Image.fromarray(lab), flip=d.flip, scaled_size=d.scaled,
+                                             pad=d.pad, crop_xy=d.crop, crop_size=crop)
+        got_im, got_lab = tt(xi, xl, d)
+        assert np.array_equal(got_im.cpu().numpy(), want_im), d
+        assert np.array_equal(got_lab.cpu().numpy(), want_lab.astype(np.int64)), d
+
+
+def test_refuses_cpu_tensors():
+    from mrfp_amd import _lib
+    from mrfp_amd.input_pipeline import Draw, TrainTransform
+    tt = TrainTransform(32)
+    with pytest.raises(_lib.MrfpHipError):
+        tt(torch.zeros(8, 8, 3, dtype=torch.uint8), torch.zeros(8, 8, dtype=torch.uint8), Draw(False, False, (8, 8), (13, 13), (0, 0), None))
