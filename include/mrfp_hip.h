@@ -294,13 +294,20 @@ int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void*
  *   mrfp_input_assemble: pad (image 0 / label `ignore`) + crop + ToTensor.  img: scaled uint8 [Hs,Ws,3]; lab: ORIGINAL
  *     uint8 label map [Hl,Wl]; ytab [Hs], xtab [Ws]: Pillow's nearest-neighbour source indices of the scaled label;
  *     the scaled image sits at (pad_x, pad_y) of the padded one, the crop starts at (x1, y1); out_img float [3,Hc,Wc]
- *     (values 0..255, no /255, as dataloaders.py:128-133), out_lab int64 [Hc,Wc].
+ *     (values 0..255, no /255, as dataloaders.py:128-133), out_lab int64 [Hc,Wc]; with out_u8 != NULL the image goes
+ *     there as uint8 [Hc,Wc,3] instead (the blur passes run before ToTensor = mrfp_u8hwc_to_f32chw).
+ *   mrfp_box_blur3_u8: one pass of ImageFilter.GaussianBlur(radius < 1) (dataloaders.py:168-177; Pillow BoxBlur.c):
+ *     out = (in*ww + (left + right)*fw + 2^23) >> 24, edges replicated; GaussianBlur = 3 horizontal + 3 vertical passes;
+ *     ww, fw from the radius as Pillow derives them (mrfp_amd/input_pipeline.py::_blur_weights).
  * ------------------------------------------------------------------------------------------- */
 int mrfp_resample_u8(const void* src, void* dst, int64_t Hin, int64_t Win, int64_t Hout, int64_t Wout, int64_t C,
                      const int32_t* bounds, const int32_t* coefs, int ksize, int vertical, int flip, void* stream);
 int mrfp_input_assemble(const void* img, const void* lab, const int32_t* ytab, const int32_t* xtab, int64_t Hs, int64_t Ws,
                         int64_t Hl, int64_t Wl, int flip, int pad_x, int pad_y, int x1, int y1, int64_t Hc, int64_t Wc, int ignore,
-                        float* out_img, int64_t* out_lab, void* stream);
+                        float* out_img, void* out_u8, int64_t* out_lab, void* stream);
+int mrfp_box_blur3_u8(const void* src, void* dst, int64_t H, int64_t W, int64_t C, int64_t ww, int64_t fw, int vertical,
+                      void* stream);
+int mrfp_u8hwc_to_f32chw(const void* src, float* dst, int64_t H, int64_t W, void* stream);
 
 #ifdef __cplusplus
 }

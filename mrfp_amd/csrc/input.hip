@@ -8,6 +8,7 @@
 // oracle/input_oracle.py); the kernels do the integer arithmetic, so the result equals PIL's byte for byte.
 //   resample_u8   one separable pass over a [H,W,C] uint8 image (the horizontal pass can read the source mirrored: the
 //                 reference flips BEFORE it scales)
+//   box_blur3     one pass of ImageFilter.GaussianBlur's box-blur approximation (radius < 1: dataloaders.py:168-177)
 //   assemble      pad (ImageOps.expand: image 0, label ignore_index) + crop + ToTensor: float32 [3,Hc,Wc] in 0..255 and the
 //                 int64 label map, the label fetched through PIL's nearest-neighbour index tables from the ORIGINAL map
 #include "common.hpp"
@@ -45,25 +46,60 @@ __global__ __launch_bounds__(256) void input_assemble_kernel(const uint8_t* __re
                                                              const int32_t* __restrict__ ytab, const int32_t* __restrict__ xtab,
                                                              int Hs, int Ws, int Hl, int Wl, int flip, int pad_x, int pad_y, int x1,
                                                              int y1, int Hc, int Wc, int ignore, float* __restrict__ out_img,
-                                                             int64_t* __restrict__ out_lab) {
+                                                             uint8_t* __restrict__ out_u8, int64_t* __restrict__ out_lab) {
     const int64_t n = (int64_t)Hc * Wc;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int ox = (int)(i % Wc), oy = (int)(i / Wc);
         const int px = x1 + ox - pad_x, py = y1 + oy - pad_y;       // position in the scaled image
         const bool inside = px >= 0 && px < Ws && py >= 0 && py < Hs;
-        float r = 0.f, g = 0.f, b = 0.f;
+        uint8_t r = 0, g = 0, b = 0;
         int64_t l = ignore;
         if (inside) {
             const uint8_t* p = img + ((int64_t)py * Ws + px) * 3;
-            r = (float)p[0]; g = (float)p[1]; b = (float)p[2];
+            r = p[0]; g = p[1]; b = p[2];
             const int sy = ytab[py], sx0 = xtab[px];
             if (sy >= 0 && sy < Hl && sx0 >= 0 && sx0 < Wl) l = lab[(int64_t)sy * Wl + (flip ? Wl - 1 - sx0 : sx0)];
             else l = 0;                                               // ImagingScaleAffine leaves such pixels of a new image zero
         }
-        out_img[i] = r;
-        out_img[n + i] = g;
-        out_img[2 * n + i] = b;
+        if (out_u8) {                                   // uint8 [Hc,Wc,3]: the blur passes come before ToTensor
+            out_u8[3 * i] = r; out_u8[3 * i + 1] = g; out_u8[3 * i + 2] = b;
+        } else {
+            out_img[i] = (float)r;
+            out_img[n + i] = (float)g;
+            out_img[2 * n + i] = (float)b;
+        }
         out_lab[i] = l;
+    }
+}
+
+// One pass of Pillow's box blur (BoxBlur.c ImagingLineBoxBlur8) for a box radius below 1 -- all ImageFilter.GaussianBlur
+// ever asks for when its radius is random.random() (dataloaders.py:172-174): out = (in*ww + (left + right)*fw + 2^23) >> 24
+// with the edge pixels replicated; GaussianBlur = 3 horizontal + 3 vertical passes, every pass rounded to 8 bits.
+__global__ __launch_bounds__(256) void box_blur3_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                           int C, unsigned ww, unsigned fw, int vertical) {
+    const int64_t n = (int64_t)H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        unsigned a, b;
+        if (vertical) {
+            a = src[((int64_t)(y > 0 ? y - 1 : 0) * W + x) * C + c];
+            b = src[((int64_t)(y < H - 1 ? y + 1 : H - 1) * W + x) * C + c];
+        } else {
+            a = src[((int64_t)y * W + (x > 0 ? x - 1 : 0)) * C + c];
+            b = src[((int64_t)y * W + (x < W - 1 ? x + 1 : W - 1)) * C + c];
+        }
+        const unsigned bulk = (unsigned)src[i] * ww + (a + b) * fw;
+        dst[i] = (uint8_t)((bulk + (1u << 23)) >> 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t npix) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        dst[i] = (float)src[3 * i];
+        dst[npix + i] = (float)src[3 * i + 1];
+        dst[2 * npix + i] = (float)src[3 * i + 2];
     }
 }
 
@@ -92,8 +128,8 @@ int mrfp_resample_u8(const void* src, void* dst, int64_t Hin, int64_t Win, int64
 
 int mrfp_input_assemble(const void* img, const void* lab, const int32_t* ytab, const int32_t* xtab, int64_t Hs, int64_t Ws,
                         int64_t Hl, int64_t Wl, int flip, int pad_x, int pad_y, int x1, int y1, int64_t Hc, int64_t Wc, int ignore,
-                        float* out_img, int64_t* out_lab, void* stream) {
-    MRFP_CHECK(img && lab && ytab && xtab && out_img && out_lab, "input_assemble: null argument");
+                        float* out_img, void* out_u8, int64_t* out_lab, void* stream) {
+    MRFP_CHECK(img && lab && ytab && xtab && (out_img || out_u8) && out_lab, "input_assemble: null argument");
     MRFP_CHECK(Hs > 0 && Ws > 0 && Hl > 0 && Wl > 0 && Hc > 0 && Wc > 0 && Hs < 65536 && Ws < 65536 && Hc < 65536 && Wc < 65536,
                "input_assemble: bad sizes");
     MRFP_CHECK(pad_x >= 0 && pad_y >= 0 && x1 >= 0 && y1 >= 0 && x1 + Wc <= Ws + 2 * pad_x && y1 + Hc <= Hs + 2 * pad_y,
@@ -104,7 +140,31 @@ int mrfp_input_assemble(const void* img, const void* lab, const int32_t* ytab, c
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(input_assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img,
                        (const uint8_t*)lab, ytab, xtab, (int)Hs, (int)Ws, (int)Hl, (int)Wl, flip, pad_x, pad_y, x1, y1, (int)Hc, (int)Wc,
-                       ignore, out_img, out_lab);
+                       ignore, out_img, (uint8_t*)out_u8, out_lab);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_box_blur3_u8(const void* src, void* dst, int64_t H, int64_t W, int64_t C, int64_t ww, int64_t fw, int vertical,
+                      void* stream) {
+    MRFP_CHECK(src && dst && src != dst && H > 0 && W > 0 && C > 0 && H < 65536 && W < 65536, "box_blur3_u8: bad arguments");
+    MRFP_CHECK(ww > 0 && fw >= 0 && ww + 2 * fw <= (1ll << 24), "box_blur3_u8: weights %lld + 2*%lld exceed 2^24 (box radius >= 1?)",
+               (long long)ww, (long long)fw);
+    const int64_t n = H * W * C;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(box_blur3_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
+                       (uint8_t*)dst, (int)H, (int)W, (int)C, (unsigned)ww, (unsigned)fw, vertical);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_u8hwc_to_f32chw(const void* src, float* dst, int64_t H, int64_t W, void* stream) {
+    MRFP_CHECK(src && dst && H > 0 && W > 0, "u8hwc_to_f32chw: bad arguments");
+    const int64_t n = H * W;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(u8hwc_to_f32chw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, dst, n);
     MRFP_LAUNCH_CHECK();
     return 0;
 }

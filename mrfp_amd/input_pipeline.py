@@ -2,11 +2,12 @@
 
 Reference: main.py:409-419 `transform_tr` = RandomHorizontalFlip -> ColorJitter -> RandomSizeAndCrop(crop_size,
 crop_nopad=False, ignore_index=255) -> Resize(crop_size) -> RandomGaussianBlur -> ToTensor (dataloaders.py).  This module
-does flip, the BICUBIC / NEAREST rescale, the ImageOps.expand padding, the crop and ToTensor on the device: uint8 image
+does flip, the BICUBIC / NEAREST rescale, the ImageOps.expand padding, the crop, the Gaussian blur and ToTensor on the device: uint8 image
 and label map in, float32 [3,H,W] (0..255) and int64 [H,W] out, byte for byte what PIL produces (tests/test_input_gpu.py).
-NOT included: ColorJitter (dataloaders.py:596-660: PIL ImageEnhance blends + an HSV round trip) and RandomGaussianBlur
-(:168-177: PIL's box-blur approximation) -- `draw()` still consumes their gates from the random stream and reports them,
-so a caller can route those samples through the CPU transform; the Resize step is the identity here (the crop already has
+RandomGaussianBlur (:168-177) is included: its radius is random.random() < 1, for which ImageFilter.GaussianBlur is three
+horizontal + three vertical passes of a 3-tap fixed-point box blur.  NOT included: ColorJitter (dataloaders.py:596-660: PIL
+ImageEnhance blends + an HSV round trip) -- `draw()` still consumes its gate from the random stream and reports it, so a
+caller can route those samples through the CPU transform; the Resize step is the identity here (the crop already has
 crop_size) and PIL returns a copy for it.
 
 The fixed-point coefficient tables of Pillow's resampler are built on the host exactly as Pillow builds them
@@ -75,6 +76,25 @@ def _nearest_table(in_size: int, out_size: int) -> np.ndarray:
     return np.where(xo < 0.0, -1, xo.astype(np.int64)).astype(np.int32)
 
 
+def _blur_weights(radius: float):
+    """ImageFilter.GaussianBlur(radius) -> the (ww, fw) 24-bit weights of its three box-blur passes per axis, derived as
+    Pillow derives them (BoxBlur.c _gaussian_blur_radius in C float arithmetic, then ww = (UINT32)(2^24 / (2 r + 1)),
+    fw = (2^24 - (2 int(r) + 1) ww) / 2).  Only box radii below 1 (every radius = random.random() gives one)."""
+    f32 = np.float32
+    r = f32(radius)
+    sigma2 = f32(f32(r * r) / f32(3))
+    L = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(math.floor((float(L) - 1.0) / 2.0))
+    a = f32(f32(f32(2) * l + f32(1)) * f32(f32(l * f32(l + f32(1))) - f32(f32(3) * sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - f32(f32(l + f32(1)) * f32(l + f32(1))))))
+    fr = f32(l + a)
+    if int(fr) != 0:
+        raise _lib.MrfpHipError("GaussianBlur radius %r gives a box radius >= 1: only the reference's range [0, 1) is built" % radius)
+    ww = int(f32(f32(1 << 24) / f32(fr * f32(2) + f32(1))))
+    fw = ((1 << 24) - ww) // 2
+    return ww, fw
+
+
 @dataclass
 class Draw:
     flip: bool
@@ -82,7 +102,7 @@ class Draw:
     scaled: Tuple[int, int]            # (w, h) after RandomSizeAndCrop's rescale
     pad: Tuple[int, int]               # (pad_w, pad_h) of ImageOps.expand on every side
     crop: Tuple[int, int]              # (x1, y1) in the padded image
-    blur: Optional[float]              # GaussianBlur radius when its gate fired (not applied on the GPU path)
+    blur: Optional[float]              # GaussianBlur radius when its gate fired
 
 
 class TrainTransform:
@@ -149,6 +169,15 @@ class TrainTransform:
             out_img = torch.empty((3, T, T), dtype=torch.float32, device=dev)
         if out_lab is None:
             out_lab = torch.empty((T, T), dtype=torch.int64, device=dev)
+        blur = d.blur is not None and d.blur != 0.0          # PIL returns a copy for radius 0
+        crop_u8 = torch.empty((T, T, 3), dtype=torch.uint8, device=dev) if blur else None
         call("mrfp_input_assemble", ptr(cur), ptr(lab_u8), ptr(ty), ptr(tx), sh, sw, H, W, int(d.flip), d.pad[0], d.pad[1],
-             d.crop[0], d.crop[1], T, T, int(self.ignore_index), ptr(out_img), ptr(out_lab), stream())
+             d.crop[0], d.crop[1], T, T, int(self.ignore_index), ptr(out_img), ptr(crop_u8), ptr(out_lab), stream())
+        if blur:                                              # RandomGaussianBlur (dataloaders.py:168-177), then ToTensor
+            ww, fw = _blur_weights(d.blur)
+            a, b = crop_u8, torch.empty_like(crop_u8)
+            for vertical in (0, 0, 0, 1, 1, 1):               # ImagingBoxBlur: three passes along x, then three along y
+                call("mrfp_box_blur3_u8", ptr(a), ptr(b), T, T, 3, ww, fw, vertical, stream())
+                a, b = b, a
+            call("mrfp_u8hwc_to_f32chw", ptr(a), ptr(out_img), T, T, stream())
         return out_img, out_lab

@@ -5,10 +5,12 @@ Two layers:
   for call -- RandomHorizontalFlip (dataloaders.py:139-150), RandomSizeAndCrop (398-435: img.resize((w, h), BICUBIC),
   mask.resize((w, h), NEAREST)), RandomCrop (257-337: ImageOps.expand borders, crop), Resize (467-482: identity here, PIL
   returns a copy when the size is unchanged), ToTensor (118-136: float32, NO division by 255) -- with the random draws
-  passed in.  ColorJitter (596-660) and RandomGaussianBlur (168-177) are NOT part of the GPU path.
+  passed in, RandomGaussianBlur (168-177) when its gate fired.  ColorJitter (596-660) is NOT part of the GPU path (DESIGN.md
+  section 8).
 * `resample_tables` / `resample_u8` / `nearest_table`: the arithmetic INSIDE those PIL calls, restated from the published
   algorithm of the third-party dependency Pillow (pinned here: 12.2.0; src/libImaging/Resample.c precompute_coeffs,
-  normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc; Geometry.c ImagingScaleAffine for NEAREST).
+  normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc; Geometry.c ImagingScaleAffine for NEAREST;
+  BoxBlur.c _gaussian_blur_radius, ImagingLineBoxBlur8 for GaussianBlur).
   Pinned against PIL itself in tests/test_input_cpu.py (bit-exact on every case).
 """
 from __future__ import annotations
@@ -103,7 +105,36 @@ def nearest_table(in_size: int, out_size: int) -> np.ndarray:
     return tab
 
 
-def transform_pil(img, mask, *, flip: bool, scaled_size, pad, crop_xy, crop_size: int, ignore_index: int = 255):
+def gaussian_box_radius(radius: float, passes: int = 3) -> np.float32:
+    """Pillow BoxBlur.c _gaussian_blur_radius: the box radius whose `passes` repetitions approximate the Gaussian (C float)."""
+    f32 = np.float32
+    r = f32(radius)
+    sigma2 = f32(f32(r * r) / f32(passes))
+    L = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(math.floor((float(L) - 1.0) / 2.0))
+    a = f32(f32(f32(2) * l + f32(1)) * f32(f32(l * f32(l + f32(1))) - f32(f32(3) * sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - f32(f32(l + f32(1)) * f32(l + f32(1))))))
+    return f32(l + a)
+
+
+def gaussian_blur_u8(img: np.ndarray, radius: float) -> np.ndarray:
+    """img.filter(ImageFilter.GaussianBlur(radius)) of an 8-bit [H,W,C] image for a box radius below 1 (ImagingBoxBlur:
+    three passes of ImagingLineBoxBlur8 along x, then three along y; every pass rounds to 8 bits, edges replicated)."""
+    f32 = np.float32
+    fr = gaussian_box_radius(radius)
+    assert int(fr) == 0, "restated for box radii < 1 only (radius = random.random() in the reference)"
+    ww = int(f32(f32(1 << 24) / f32(fr * f32(2) + f32(1))))
+    fw = ((1 << 24) - ww) // 2
+    out = img
+    for axis in (1, 1, 1, 0, 0, 0):
+        x = np.moveaxis(out, axis, 0).astype(np.int64)
+        left, right = np.concatenate([x[:1], x[:-1]]), np.concatenate([x[1:], x[-1:]])
+        y = ((x * ww + (left + right) * fw + (1 << 23)) >> 24).astype(np.uint8)
+        out = np.moveaxis(y, 0, axis)
+    return out
+
+
+def transform_pil(img, mask, *, flip: bool, scaled_size, pad, crop_xy, crop_size: int, ignore_index: int = 255, blur=None):
     """The reference's PIL calls for one sample with the draws given: img / mask are PIL images ('RGB' / 'L').
     -> (float32 [3,Hc,Wc] in 0..255, float32 [Hc,Wc]) as dataloaders.py ToTensor returns them."""
     from PIL import Image, ImageOps
@@ -121,5 +152,8 @@ def transform_pil(img, mask, *, flip: bool, scaled_size, pad, crop_xy, crop_size
         img = img.crop((x1, y1, x1 + crop_size, y1 + crop_size))
         mask = mask.crop((x1, y1, x1 + crop_size, y1 + crop_size))
     img, mask = img.resize((crop_size, crop_size), Image.BILINEAR), mask.resize((crop_size, crop_size), Image.NEAREST)  # :479-480
+    if blur is not None:                                                 # RandomGaussianBlur :172-174
+        from PIL import ImageFilter
+        img = img.filter(ImageFilter.GaussianBlur(radius=blur))
     im = np.array(img).astype(np.float32).transpose((2, 0, 1))          # ToTensor :128-133
     return im, np.array(mask).astype(np.float32)

@@ -66,3 +66,18 @@ def test_transform_pil_shapes_and_padding():
     im, lab = io.transform_pil(img, mask, flip=True, scaled_size=(45, 30), pad=(10, 18), crop_xy=(1, 2), crop_size=64)
     assert im.shape == (3, 64, 64) and lab.shape == (64, 64) and im.dtype == np.float32
     assert (lab == 255).any() and (im[:, lab == 255] == 0).all()        # the border: ignore label, black pixels
+
+
+def test_gaussian_blur_restatement_equals_pil():
+    from PIL import ImageFilter
+    from mrfp_amd import input_pipeline as ip
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (29, 37, 3), dtype=np.uint8)
+    r = random.Random(2)
+    for radius in [r.random() for _ in range(12)] + [1e-3, 0.999]:
+        ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=radius)))
+        assert np.array_equal(io.gaussian_blur_u8(img, radius), ref), radius
+        f32 = np.float32
+        fr = io.gaussian_box_radius(radius)
+        ww = int(f32(f32(1 << 24) / f32(fr * f32(2) + f32(1))))
+        assert ip._blur_weights(radius) == (ww, ((1 << 24) - ww) // 2)

@@ -25,11 +25,11 @@ def test_train_transform_equals_pil(H, W, crop):
     r = random.Random(7)
     draws = [tt.draw(W, H, r) for _ in range(10)]
     draws.append(Draw(True, False, (W, H), ((crop - W) // 2 + 1 if crop > W else 0, (crop - H) // 2 + 1 if crop > H else 0),
-                      (0, 0), None))                                  # scale exactly 1: mirrored copy only
+                      (0, 0), 0.37))                                  # scale exactly 1: mirrored copy only; blurred
     xi, xl = torch.from_numpy(img).to(DEV), torch.from_numpy(lab).to(DEV)
     for d in draws:
         want_im, want_lab = io.transform_pil(Image.fromarray(img), Image.fromarray(lab), flip=d.flip, scaled_size=d.scaled,
-                                             pad=d.pad, crop_xy=d.crop, crop_size=crop)
+                                             pad=d.pad, crop_xy=d.crop, crop_size=crop, blur=d.blur)
         got_im, got_lab = tt(xi, xl, d)
         assert np.array_equal(got_im.cpu().numpy(), want_im), d
         assert np.array_equal(got_lab.cpu().numpy(), want_lab.astype(np.int64)), d
