@@ -284,7 +284,7 @@ int mrfp_fourier_mix(const void* x, void* y, const int64_t* perm, void* S, void*
                      float radius, float lam, int high, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Geometric part of the training input pipeline, bit-exact with the PIL calls of the reference (main.py:409-419
+ * The training input pipeline (transform_tr), bit-exact with the PIL calls of the reference (main.py:409-419
  * transform_tr: dataloaders.py:139-150 flip, 398-435 RandomSizeAndCrop = img.resize(BICUBIC) / mask.resize(NEAREST),
  * 257-337 RandomCrop with ImageOps.expand padding, 118-136 ToTensor).  Pillow resizes 8-bit images in two separable
  * fixed-point passes: out = clip8((2^21 + sum_t in[lo + t] * coefs[o][t]) >> 22), horizontal first.
@@ -308,6 +308,10 @@ int mrfp_input_assemble(const void* img, const void* lab, const int32_t* ytab, c
 int mrfp_box_blur3_u8(const void* src, void* dst, int64_t H, int64_t W, int64_t C, int64_t ww, int64_t fw, int vertical,
                       void* stream);
 int mrfp_u8hwc_to_f32chw(const void* src, float* dst, int64_t H, int64_t W, void* stream);
+/* One ColorJitter step on a uint8 [npix,3] image (dataloaders.py:491-660; Pillow ImageEnhance = Image.blend with a degenerate
+ * image, Convert.c rgb2hsv / hsv2rgb): op 0 brightness, 1 contrast (needs ws: 16 bytes, the L mean is reduced on the device),
+ * 2 saturation, 3 hue (shift = uint8(hue_factor * 255), factor unused).  Byte-exact with PIL. */
+int mrfp_jitter_u8(const void* src, void* dst, int64_t npix, int op, float factor, int shift, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-// input.hip -- geometric part of the training input pipeline on the GPU, bit-exact with the PIL calls the reference makes
+// input.hip -- the training input pipeline (transform_tr) on the GPU, bit-exact with the PIL calls the reference makes
 // (main.py:409-419 transform_tr; dataloaders.py:139-150 RandomHorizontalFlip, 398-435 RandomSizeAndCrop -> img.resize(BICUBIC)
 // / mask.resize(NEAREST), 257-337 RandomCrop with ImageOps.expand padding, 467-482 Resize, 118-136 ToTensor).
 //
@@ -103,6 +103,85 @@ __global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const uint8_t* __r
     }
 }
 
+// ---- ColorJitter (dataloaders.py:491-660): PIL ImageEnhance blends and the HSV round trip, per pixel ---------------------
+// ImageEnhance.X(img).enhance(f) = Image.blend(degenerate, img, f) = clip8((float)d + f * (float)(p - d)) per byte (Blend.c,
+// C float arithmetic), with d = 0 (Brightness), the rounded mean of the L image (Contrast) or the pixel's own L (Color);
+// L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16 (Convert.c).  adjust_hue: RGB -> HSV (Convert.c rgb2hsv: float / double
+// mix as in the C source), H += shift (uint8 wrap), HSV -> RGB.  Restated in oracle/input_oracle.py and pinned against PIL
+// there (the two conversions on all 2^24 triples).
+__device__ __forceinline__ int pil_l(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+__device__ __forceinline__ uint8_t pil_blend(int d, int p, float alpha) {
+    const float t = (float)d + alpha * (float)(p - d);
+    return (uint8_t)(t <= 0.f ? 0 : t >= 255.f ? 255 : (int)t);
+}
+
+__global__ __launch_bounds__(256) void gray_sum_kernel(const uint8_t* __restrict__ src, int64_t npix, unsigned long long* __restrict__ sum) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256)
+        acc += (unsigned)pil_l(src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);          // integer sum: exact in any order
+}
+__global__ void gray_mean_kernel(const unsigned long long* __restrict__ sum, int64_t npix, int* __restrict__ gray) {
+    *gray = (int)((double)*sum / (double)npix + 0.5);                  // int(ImageStat.Stat(L).mean[0] + 0.5)
+}
+
+// op: 0 brightness, 1 contrast (*gray), 2 saturation (own L), 3 hue (shift)
+__global__ __launch_bounds__(256) void jitter_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int64_t npix, int op,
+                                                        float alpha, int shift, const int* __restrict__ gray) {
+    const int gm = (op == 1) ? *gray : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        const int r = src[3 * i], g = src[3 * i + 1], b = src[3 * i + 2];
+        uint8_t o0, o1, o2;
+        if (op < 3) {
+            const int d = op == 0 ? 0 : op == 1 ? gm : pil_l(r, g, b);
+            o0 = pil_blend(d, r, alpha); o1 = pil_blend(d, g, alpha); o2 = pil_blend(d, b, alpha);
+        } else {
+            const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+            int uh = 0, us = 0;
+            const int uv = maxc;
+            if (minc != maxc) {
+                const float cr = (float)(maxc - minc);
+                const float sf = cr / (float)maxc;
+                const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+                float h;
+                if (r == maxc) h = bc - gc;
+                else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+                else h = (float)(4.0 + (double)gc - (double)rc);
+                const double hd = (double)h / 6.0 + 1.0;
+                h = (float)(hd - floor(hd));                           // fmod(., 1.0) of a positive number
+                uh = (int)((double)h * 255.0);
+                us = (int)((double)sf * 255.0);
+                uh = uh < 0 ? 0 : uh > 255 ? 255 : uh;
+                us = us < 0 ? 0 : us > 255 ? 255 : us;
+            }
+            uh = (uh + shift) & 255;                                   // np_h += np.uint8(hue_factor * 255)
+            if (us == 0) {
+                o0 = o1 = o2 = (uint8_t)uv;
+            } else {
+                const float fs = (float)us / 255.0f;
+                const double hh = (double)uh * 6.0 / 255.0;
+                const int ii = (int)floor(hh);
+                const float f = (float)(hh - (double)ii);
+                const float vf = (float)uv;
+                const double pd = round((double)(vf * (1.0f - fs))), qd = round((double)(vf * (1.0f - fs * f))),
+                             td = round((double)(vf * (1.0f - fs * (1.0f - f))));
+                const uint8_t pp = (uint8_t)(pd < 0 ? 0 : pd > 255 ? 255 : pd), qq = (uint8_t)(qd < 0 ? 0 : qd > 255 ? 255 : qd),
+                              tt = (uint8_t)(td < 0 ? 0 : td > 255 ? 255 : td), vv = (uint8_t)uv;
+                switch (ii % 6) {
+                    case 0: o0 = vv; o1 = tt; o2 = pp; break;
+                    case 1: o0 = qq; o1 = vv; o2 = pp; break;
+                    case 2: o0 = pp; o1 = vv; o2 = tt; break;
+                    case 3: o0 = pp; o1 = qq; o2 = vv; break;
+                    case 4: o0 = tt; o1 = pp; o2 = vv; break;
+                    default: o0 = vv; o1 = pp; o2 = qq; break;
+                }
+            }
+        }
+        dst[3 * i] = o0; dst[3 * i + 1] = o1; dst[3 * i + 2] = o2;
+    }
+}
+
 }  // namespace mrfp
 
 using namespace mrfp;
@@ -155,6 +234,27 @@ int mrfp_box_blur3_u8(const void* src, void* dst, int64_t H, int64_t W, int64_t 
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(box_blur3_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
                        (uint8_t*)dst, (int)H, (int)W, (int)C, (unsigned)ww, (unsigned)fw, vertical);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+int mrfp_jitter_u8(const void* src, void* dst, int64_t npix, int op, float factor, int shift, void* ws, void* stream) {
+    MRFP_CHECK(src && dst && npix > 0 && op >= 0 && op <= 3, "jitter_u8: bad arguments (op 0..3)");
+    MRFP_CHECK(op != 1 || ws, "jitter_u8: the contrast op needs 16 bytes of workspace");
+    MRFP_CHECK(op != 3 || (shift >= 0 && shift < 256), "jitter_u8: hue shift must be in 0..255");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = (npix + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    int* gray = nullptr;
+    if (op == 1) {
+        unsigned long long* sum = (unsigned long long*)ws;
+        gray = (int*)((char*)ws + 8);
+        if (hipMemsetAsync(sum, 0, 8, st) != hipSuccess) { set_error("jitter_u8: hipMemsetAsync failed"); return -1; }
+        hipLaunchKernelGGL(gray_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint8_t*)src, npix, sum);
+        hipLaunchKernelGGL(gray_mean_kernel, dim3(1), dim3(1), 0, st, (const unsigned long long*)sum, npix, gray);
+    }
+    hipLaunchKernelGGL(jitter_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint8_t*)src, (uint8_t*)dst, npix, op, factor,
+                       shift, (const int*)gray);
     MRFP_LAUNCH_CHECK();
     return 0;
 }

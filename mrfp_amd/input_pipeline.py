@@ -1,14 +1,15 @@
-"""Geometric part of the reference's training transform on the GPU, bit-exact with its PIL calls.
+"""The reference's training transform (main.py:409-419 transform_tr) on the GPU, bit-exact with its PIL calls.
 
 Reference: main.py:409-419 `transform_tr` = RandomHorizontalFlip -> ColorJitter -> RandomSizeAndCrop(crop_size,
 crop_nopad=False, ignore_index=255) -> Resize(crop_size) -> RandomGaussianBlur -> ToTensor (dataloaders.py).  This module
-does flip, the BICUBIC / NEAREST rescale, the ImageOps.expand padding, the crop, the Gaussian blur and ToTensor on the device: uint8 image
+does flip, ColorJitter, the BICUBIC / NEAREST rescale, the ImageOps.expand padding, the crop, the Gaussian blur and ToTensor on the device: uint8 image
 and label map in, float32 [3,H,W] (0..255) and int64 [H,W] out, byte for byte what PIL produces (tests/test_input_gpu.py).
 RandomGaussianBlur (:168-177) is included: its radius is random.random() < 1, for which ImageFilter.GaussianBlur is three
-horizontal + three vertical passes of a 3-tap fixed-point box blur.  NOT included: ColorJitter (dataloaders.py:596-660: PIL
-ImageEnhance blends + an HSV round trip) -- `draw()` still consumes its gate from the random stream and reports it, so a
-caller can route those samples through the CPU transform; the Resize step is the identity here (the crop already has
-crop_size) and PIL returns a copy for it.
+horizontal + three vertical passes of a 3-tap fixed-point box blur.  ColorJitter (dataloaders.py:596-660) is included: PIL's
+ImageEnhance blends (Blend.c float arithmetic) and the RGB -> HSV -> RGB round trip of adjust_hue (Convert.c), per pixel,
+the contrast mean reduced on the device; the Resize step is the identity here (the crop already has crop_size) and PIL
+returns a copy for it.  One deviation is stated in oracle/input_oracle.py::hue_shift: `np.uint8(hue_factor * 255)` of a
+negative factor is taken with the wrap-around of the numpy 1.x the reference pins.
 
 The fixed-point coefficient tables of Pillow's resampler are built on the host exactly as Pillow builds them
 (src/libImaging/Resample.c, double precision) and cached per (source size, destination size); the kernels
@@ -95,10 +96,13 @@ def _blur_weights(radius: float):
     return ww, fw
 
 
+_JITTER_OPS = {"brightness": 0, "contrast": 1, "saturation": 2, "hue": 3}
+
+
 @dataclass
 class Draw:
     flip: bool
-    jitter: bool                       # ColorJitter gate (not applied on the GPU path)
+    jitter: Optional[list]             # ColorJitter: [(op, factor), ...] in application order when its gate fired, else None
     scaled: Tuple[int, int]            # (w, h) after RandomSizeAndCrop's rescale
     pad: Tuple[int, int]               # (pad_w, pad_h) of ImageOps.expand on every side
     crop: Tuple[int, int]              # (x1, y1) in the padded image
@@ -106,16 +110,28 @@ class Draw:
 
 
 class TrainTransform:
-    """transform_tr of the reference (main.py:409-419) without ColorJitter / GaussianBlur, on the device."""
+    """transform_tr of the reference (main.py:409-419) on the device."""
 
     def __init__(self, crop_size: int, scale_min: float = 0.5, scale_max: float = 2.0, ignore_index: int = 255):
         self.crop_size, self.scale_min, self.scale_max, self.ignore_index = int(crop_size), scale_min, scale_max, ignore_index
         self._dev_tables = {}
 
-    def draw(self, w: int, h: int, rng=_random) -> Draw:
-        """Consumes python's `random` stream in the reference's order (dataloaders.py:145, 655, 421, 327-331, 172-174)."""
+    JITTER = dict(brightness=0.5, hue=0.3, contrast=0.2, saturation=0.2)      # main.py:412
+
+    def draw(self, w: int, h: int, rng=_random, np_rng=np.random) -> Draw:
+        """Consumes python's `random` stream in the reference's order (dataloaders.py:145, 655, 421, 327-331, 172-174) and,
+        when the ColorJitter gate fires, numpy's global stream as get_params does (:622-643: four uniform factors, then
+        np.random.shuffle of the four transforms)."""
         flip = rng.random() < 0.5
-        jitter = rng.random() < 0.5                       # its factors come from np.random, not from this stream
+        jitter = None
+        if rng.random() < 0.5:
+            j = self.JITTER
+            ops = [("brightness", float(np_rng.uniform(max(0, 1 - j["brightness"]), 1 + j["brightness"]))),
+                   ("contrast", float(np_rng.uniform(max(0, 1 - j["contrast"]), 1 + j["contrast"]))),
+                   ("saturation", float(np_rng.uniform(max(0, 1 - j["saturation"]), 1 + j["saturation"]))),
+                   ("hue", float(np_rng.uniform(-j["hue"], j["hue"])))]
+            np_rng.shuffle(ops)                            # consumes the stream as shuffling the four Lambdas does
+            jitter = ops
         scale_amt = 1.0 * rng.uniform(self.scale_min, self.scale_max)
         sw, sh = int(w * scale_amt), int(h * scale_amt)
         t = self.crop_size
@@ -156,6 +172,13 @@ class TrainTransform:
         sw, sh = d.scaled
         bx, kx, by, ky, tx, ty, ksx, ksy = self._tables(dev, H, W, sh, sw)
         cur = img_u8
+        if d.jitter:                                       # ColorJitter on the original-size image (per-pixel: commutes with the flip)
+            ws = torch.empty(16, dtype=torch.uint8, device=dev)
+            for op, factor in d.jitter:
+                nxt = torch.empty_like(cur)
+                shift = int(factor * 255) & 255 if op == "hue" else 0
+                call("mrfp_jitter_u8", ptr(cur), ptr(nxt), H * W, _JITTER_OPS[op], float(factor), shift, ptr(ws), stream())
+                cur = nxt
         if sw != W or d.flip:       # horizontal pass first (Pillow ImagingResample), reading the source mirrored when flipped
             # (at sw == W the coefficients are exactly (0, 1, 0): the pass is then a plain mirrored copy)
             tmp = torch.empty((H, sw, 3), dtype=torch.uint8, device=dev)

@@ -1,16 +1,16 @@
-"""CPU oracle of the training input pipeline's geometric part -- TEST INFRASTRUCTURE ONLY (imported by tests/ only).
+"""CPU oracle of the training input pipeline (transform_tr) -- TEST INFRASTRUCTURE ONLY (imported by tests/ and tools/input_micro.py's CPU baseline only).
 
 Two layers:
 * `transform_pil`: the reference's own sequence of PIL calls for one sample (main.py:409-419 transform_tr), restated call
   for call -- RandomHorizontalFlip (dataloaders.py:139-150), RandomSizeAndCrop (398-435: img.resize((w, h), BICUBIC),
   mask.resize((w, h), NEAREST)), RandomCrop (257-337: ImageOps.expand borders, crop), Resize (467-482: identity here, PIL
   returns a copy when the size is unchanged), ToTensor (118-136: float32, NO division by 255) -- with the random draws
-  passed in, RandomGaussianBlur (168-177) when its gate fired.  ColorJitter (596-660) is NOT part of the GPU path (DESIGN.md
-  section 8).
+  passed in: ColorJitter (596-660: the drawn list of (op, factor)), RandomGaussianBlur (168-177) when its gate fired.
 * `resample_tables` / `resample_u8` / `nearest_table`: the arithmetic INSIDE those PIL calls, restated from the published
   algorithm of the third-party dependency Pillow (pinned here: 12.2.0; src/libImaging/Resample.c precompute_coeffs,
   normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc; Geometry.c ImagingScaleAffine for NEAREST;
-  BoxBlur.c _gaussian_blur_radius, ImagingLineBoxBlur8 for GaussianBlur).
+  BoxBlur.c _gaussian_blur_radius, ImagingLineBoxBlur8 for GaussianBlur; Blend.c ImagingBlend, Convert.c rgb2l /
+  rgb2hsv / hsv2rgb for ColorJitter).
   Pinned against PIL itself in tests/test_input_cpu.py (bit-exact on every case).
 """
 from __future__ import annotations
@@ -134,12 +134,108 @@ def gaussian_blur_u8(img: np.ndarray, radius: float) -> np.ndarray:
     return out
 
 
-def transform_pil(img, mask, *, flip: bool, scaled_size, pad, crop_xy, crop_size: int, ignore_index: int = 255, blur=None):
+# ---- ColorJitter (dataloaders.py:491-660) --------------------------------------------------------------------------
+def pil_blend(d: np.ndarray, p: np.ndarray, alpha: float) -> np.ndarray:
+    """Image.blend(degenerate, image, alpha) per byte (Pillow Blend.c, C float arithmetic, clipped)."""
+    a = np.float32(alpha)
+    t = d.astype(np.float32) + a * (p.astype(np.int32) - d.astype(np.int32)).astype(np.float32)
+    return np.where(t <= 0.0, 0, np.where(t >= 255.0, 255, t.astype(np.int32))).astype(np.uint8)
+
+
+def pil_l(img: np.ndarray) -> np.ndarray:
+    r, g, b = [img[..., i].astype(np.int64) for i in range(3)]
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)       # Convert.c rgb2l
+
+
+def rgb2hsv(img: np.ndarray) -> np.ndarray:
+    """Pillow Convert.c rgb2hsv_row (float variables, double constants as in the C source)."""
+    f32 = np.float32
+    r, g, b = [img[..., i] for i in range(3)]
+    maxc = np.maximum(r, np.maximum(g, b))
+    minc = np.minimum(r, np.minimum(g, b))
+    gray = maxc == minc
+    cr = (maxc.astype(np.int32) - minc.astype(np.int32)).astype(np.float32)
+    crs = np.where(gray, f32(1), cr)
+    s = cr / np.where(gray, f32(1), maxc.astype(np.float32))
+    rc, gc, bc = [(maxc.astype(np.int32) - c).astype(np.float32) / crs for c in (r, g, b)]
+    h = np.where(r == maxc, (bc - gc).astype(np.float64),
+                 np.where(g == maxc, 2.0 + rc.astype(np.float64) - bc.astype(np.float64),
+                          4.0 + gc.astype(np.float64) - rc.astype(np.float64))).astype(np.float32)
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    us = np.clip((s.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    return np.stack([np.where(gray, 0, uh), np.where(gray, 0, us), maxc], -1).astype(np.uint8)
+
+
+def hsv2rgb(hsv: np.ndarray) -> np.ndarray:
+    """Pillow Convert.c hsv2rgb (following colorsys.py; float arithmetic, round())."""
+    f32 = np.float32
+    h, s, v = hsv[..., 0].astype(np.float64), hsv[..., 1], hsv[..., 2]
+    fs = s.astype(np.float32) / f32(255.0)
+    hh = h * 6.0 / 255.0
+    i = np.floor(hh).astype(np.int64)
+    f = (hh - i).astype(np.float32)
+    vf = v.astype(np.float32)
+
+    def rnd(x):
+        return np.clip(np.round(x.astype(np.float64)), 0, 255).astype(np.uint8)
+    p, q, t = rnd(vf * (f32(1.0) - fs)), rnd(vf * (f32(1.0) - fs * f)), rnd(vf * (f32(1.0) - fs * (f32(1.0) - f)))
+    im = i % 6
+    sel = [im == k for k in range(6)]
+    r = np.select(sel, [v, q, p, p, t, v])
+    g = np.select(sel, [t, v, v, q, p, p])
+    b = np.select(sel, [p, p, t, v, v, q])
+    gray = s == 0
+    return np.stack([np.where(gray, v, r), np.where(gray, v, g), np.where(gray, v, b)], -1).astype(np.uint8)
+
+
+def hue_shift(hue_factor: float) -> int:
+    """np.uint8(hue_factor * 255) of dataloaders.py:588 with the wrap-around of the numpy the reference pins (1.x: a C
+    cast through int): truncation toward zero, modulo 256."""
+    return int(hue_factor * 255) & 255
+
+
+def jitter_u8(img: np.ndarray, op: str, factor: float) -> np.ndarray:
+    """One adjust_* call of dataloaders.py:491-594 on an 8-bit RGB array."""
+    if op == "brightness":                                   # ImageEnhance.Brightness: degenerate = black
+        return pil_blend(np.zeros_like(img), img, factor)
+    if op == "contrast":                                     # ImageEnhance.Contrast: degenerate = int(mean(L) + 0.5)
+        L = pil_l(img)
+        mean = int(int(L.astype(np.int64).sum()) / L.size + 0.5)
+        return pil_blend(np.full_like(img, mean), img, factor)
+    if op == "saturation":                                   # ImageEnhance.Color: degenerate = L replicated
+        return pil_blend(np.repeat(pil_l(img)[..., None], 3, -1), img, factor)
+    if op == "hue":
+        hsv = rgb2hsv(img)
+        hsv[..., 0] = (hsv[..., 0].astype(np.int64) + hue_shift(factor)) & 255
+        return hsv2rgb(hsv)
+    raise ValueError(op)
+
+
+def jitter_pil(img, op: str, factor: float):
+    """The same call through PIL, as the reference makes it."""
+    from PIL import Image, ImageEnhance
+    if op == "brightness":
+        return ImageEnhance.Brightness(img).enhance(factor)
+    if op == "contrast":
+        return ImageEnhance.Contrast(img).enhance(factor)
+    if op == "saturation":
+        return ImageEnhance.Color(img).enhance(factor)
+    h, s, v = img.convert("HSV").split()                     # adjust_hue :584-591
+    np_h = np.array(h, dtype=np.uint8)
+    np_h = ((np_h.astype(np.int64) + hue_shift(factor)) & 255).astype(np.uint8)
+    return Image.merge("HSV", (Image.fromarray(np_h, "L"), s, v)).convert("RGB")
+
+
+def transform_pil(img, mask, *, flip: bool, scaled_size, pad, crop_xy, crop_size: int, ignore_index: int = 255, blur=None,
+                  jitter=None):
     """The reference's PIL calls for one sample with the draws given: img / mask are PIL images ('RGB' / 'L').
     -> (float32 [3,Hc,Wc] in 0..255, float32 [Hc,Wc]) as dataloaders.py ToTensor returns them."""
     from PIL import Image, ImageOps
     if flip:                                                             # dataloaders.py:145-147
         img, mask = img.transpose(Image.FLIP_LEFT_RIGHT), mask.transpose(Image.FLIP_LEFT_RIGHT)
+    for op, factor in (jitter or []):                                    # ColorJitter :596-660 (ops in the drawn order)
+        img = jitter_pil(img, op, factor)
     w, h = scaled_size
     img, mask = img.resize((w, h), Image.BICUBIC), mask.resize((w, h), Image.NEAREST)      # :427
     pad_w, pad_h = pad

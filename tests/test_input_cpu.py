@@ -44,9 +44,14 @@ def test_draw_follows_the_reference_order():
     tt = TrainTransform(64, 0.5, 2.0, 255)
     for seed in range(20):
         r1, r2 = random.Random(seed), random.Random(seed)
-        d = tt.draw(100, 80, r1)
+        n1, n2 = np.random.RandomState(seed), np.random.RandomState(seed)
+        d = tt.draw(100, 80, r1, n1)
         flip = r2.random() < 0.5
-        jit = r2.random() < 0.5
+        jit = None
+        if r2.random() < 0.5:                              # ColorJitter.__call__ gate, then get_params (:622-643)
+            jit = [("brightness", n2.uniform(0.5, 1.5)), ("contrast", n2.uniform(0.8, 1.2)), ("saturation", n2.uniform(0.8, 1.2)),
+                   ("hue", n2.uniform(-0.3, 0.3))]
+            n2.shuffle(jit)
         s = 1.0 * r2.uniform(0.5, 2.0)
         w, h = int(100 * s), int(80 * s)
         pad_h = (64 - h) // 2 + 1 if 64 > h else 0
@@ -56,7 +61,7 @@ def test_draw_follows_the_reference_order():
         y1 = 0 if H2 == 64 else r2.randint(0, H2 - 64)
         blur = r2.random() if r2.random() < 0.5 else None
         assert (d.flip, d.jitter, d.scaled, d.pad, d.crop, d.blur) == (flip, jit, (w, h), (pad_w, pad_h), (x1, y1), blur)
-        assert r1.random() == r2.random()                  # both streams are at the same position
+        assert r1.random() == r2.random() and n1.uniform() == n2.uniform()      # all streams are at the same position
 
 
 def test_transform_pil_shapes_and_padding():
@@ -81,3 +86,20 @@ def test_gaussian_blur_restatement_equals_pil():
         fr = io.gaussian_box_radius(radius)
         ww = int(f32(f32(1 << 24) / f32(fr * f32(2) + f32(1))))
         assert ip._blur_weights(radius) == (ww, ((1 << 24) - ww) // 2)
+
+
+def test_color_jitter_restatement_equals_pil():
+    """Blend.c / Convert.c restated: every adjust_* call of dataloaders.py:491-594 against PIL (the two colour-space
+    conversions also on every one of the 2^24 triples)."""
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (45, 61, 3), dtype=np.uint8)
+    img[:6] = img[:6, :, :1]                               # grey pixels: the s == 0 branches
+    pim = Image.fromarray(img)
+    r = random.Random(4)
+    for op, lo, hi in (("brightness", 0.5, 1.5), ("contrast", 0.8, 1.2), ("saturation", 0.8, 1.2), ("hue", -0.3, 0.3)):
+        for f in [lo, hi, 1.0 if op != "hue" else 0.0] + [r.uniform(lo, hi) for _ in range(6)]:
+            assert np.array_equal(io.jitter_u8(img, op, f), np.asarray(io.jitter_pil(pim, op, f))), (op, f)
+    a = np.arange(1 << 24, dtype=np.uint32)
+    tri = np.stack([(a >> 16) & 255, (a >> 8) & 255, a & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert np.array_equal(io.rgb2hsv(tri), np.asarray(Image.fromarray(tri).convert("HSV")))
+    assert np.array_equal(io.hsv2rgb(tri), np.asarray(Image.fromarray(tri, "HSV").convert("RGB")))

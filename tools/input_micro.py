@@ -1,4 +1,4 @@
-"""Timing of the GPU input transform (flip + PIL-exact bicubic rescale + pad + crop + ToTensor) against the same PIL calls
+"""Timing of the GPU input transform (the reference's transform_tr, byte-exact with PIL) against the same PIL calls
 on one host core.    python tools/input_micro.py [H W crop reps]"""
 import json
 import os
@@ -43,10 +43,10 @@ def main():
     pi, pl = Image.fromarray(img), Image.fromarray(lab)
     t0 = time.perf_counter()
     for d in draws:
-        io.transform_pil(pi, pl, flip=d.flip, scaled_size=d.scaled, pad=d.pad, crop_xy=d.crop, crop_size=crop, blur=d.blur)
+        io.transform_pil(pi, pl, flip=d.flip, scaled_size=d.scaled, pad=d.pad, crop_xy=d.crop, crop_size=crop, blur=d.blur, jitter=d.jitter)
     cpu_ms = (time.perf_counter() - t0) / reps * 1e3
     mean_scale = float(np.mean([d.scaled[0] / W for d in draws]))
-    print(json.dumps({"op": "input transform (flip, bicubic rescale, pad, crop, Gaussian blur on half the draws, ToTensor)", "source": [H, W], "crop": crop,
+    print(json.dumps({"op": "transform_tr (flip, ColorJitter and Gaussian blur on half the draws each, bicubic rescale, pad, crop, ToTensor)", "source": [H, W], "crop": crop,
                       "mean_scale": round(mean_scale, 3), "gpu_ms_per_image": round(gpu_ms, 3), "gpu_ms_per_image_new_tables": round(cold_ms, 3),
                       "pil_ms_per_image_one_core": round(cpu_ms, 2), "gpu_images_per_s": round(1e3 / gpu_ms, 1)}))
 
