@@ -1,4 +1,4 @@
-"""CPU oracle of the training input pipeline (transform_tr) -- TEST INFRASTRUCTURE ONLY (imported by tests/ and tools/input_micro.py's CPU baseline only).
+"""CPU oracle of the training input pipeline (transform_tr) -- TEST INFRASTRUCTURE ONLY (imported by tests/ only).
 
 Two layers:
 * `transform_pil`: the reference's own sequence of PIL calls for one sample (main.py:409-419 transform_tr), restated call

@@ -11,7 +11,30 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mrfp_amd.input_pipeline import TrainTransform  # noqa: E402
-from oracle import input_oracle as io  # noqa: E402  (timed here as the CPU baseline only)
+
+
+def pil_calls(img, mask, d, crop, ignore=255):
+    """The reference's PIL calls for one draw (dataloaders.py: flip, ColorJitter, resize, expand, crop, blur, ToTensor)."""
+    from PIL import Image, ImageEnhance, ImageFilter, ImageOps
+    if d.flip:
+        img, mask = img.transpose(Image.FLIP_LEFT_RIGHT), mask.transpose(Image.FLIP_LEFT_RIGHT)
+    for op, f in (d.jitter or []):
+        if op == "hue":
+            h, s, v = img.convert("HSV").split()
+            nh = ((np.array(h, dtype=np.int64) + (int(f * 255) & 255)) & 255).astype(np.uint8)
+            img = Image.merge("HSV", (Image.fromarray(nh, "L"), s, v)).convert("RGB")
+        else:
+            enh = {"brightness": ImageEnhance.Brightness, "contrast": ImageEnhance.Contrast, "saturation": ImageEnhance.Color}[op]
+            img = enh(img).enhance(f)
+    img, mask = img.resize(d.scaled, Image.BICUBIC), mask.resize(d.scaled, Image.NEAREST)
+    if d.pad[0] or d.pad[1]:
+        b = (d.pad[0], d.pad[1], d.pad[0], d.pad[1])
+        img, mask = ImageOps.expand(img, border=b, fill=(0, 0, 0)), ImageOps.expand(mask, border=b, fill=ignore)
+    x1, y1 = d.crop
+    img, mask = img.crop((x1, y1, x1 + crop, y1 + crop)), mask.crop((x1, y1, x1 + crop, y1 + crop))
+    if d.blur is not None:
+        img = img.filter(ImageFilter.GaussianBlur(radius=d.blur))
+    return np.array(img).astype(np.float32).transpose((2, 0, 1)), np.array(mask).astype(np.float32)
 
 
 def main():
@@ -43,7 +66,7 @@ def main():
     pi, pl = Image.fromarray(img), Image.fromarray(lab)
     t0 = time.perf_counter()
     for d in draws:
-        io.transform_pil(pi, pl, flip=d.flip, scaled_size=d.scaled, pad=d.pad, crop_xy=d.crop, crop_size=crop, blur=d.blur, jitter=d.jitter)
+        pil_calls(pi, pl, d, crop)
     cpu_ms = (time.perf_counter() - t0) / reps * 1e3
     mean_scale = float(np.mean([d.scaled[0] / W for d in draws]))
     print(json.dumps({"op": "transform_tr (flip, ColorJitter and Gaussian blur on half the draws each, bicubic rescale, pad, crop, ToTensor)", "source": [H, W], "crop": crop,
