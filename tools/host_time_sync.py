@@ -17,6 +17,11 @@ model.rng = deepv3.InjectedRandom((True, True, True), None, reinit=True)
 trainer = Trainer(model)
 x, y = synth.synth_batch(16, 768, 768, seed=1)
 x, y = x.to(dev), y.to(dev)
+import contextlib as _cl
+hp = os.environ.get("MRFP_HIPRIO")
+ctx = torch.cuda.stream(torch.cuda.Stream(priority=int(hp))) if hp else _cl.nullcontext()
+print("priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else None)
+ctx.__enter__()
 for _ in range(3):
     trainer.step(x, y)
 torch.cuda.synchronize()
@@ -26,5 +31,6 @@ for _ in range(n):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("pg=%s " % os.environ.get("MRFP_INIT_PG") + "sync=%s host issue %.1f ms/step, total %.1f ms/step" % (os.environ.get("MRFP_FORCE_SYNC"), 1e3 * (t1 - t0) / n, 1e3 * (t2 - t0) / n))
+ctx.__exit__(None, None, None)
+print("hiprio=%s " % hp + "pg=%s " % os.environ.get("MRFP_INIT_PG") + "sync=%s host issue %.1f ms/step, total %.1f ms/step" % (os.environ.get("MRFP_FORCE_SYNC"), 1e3 * (t1 - t0) / n, 1e3 * (t2 - t0) / n))
 if dist.is_initialized(): dist.destroy_process_group()
