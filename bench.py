@@ -36,8 +36,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--trunk", default="resnet-101", choices=["resnet-50", "resnet-101", "wider_resnet38_a2"])
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--width", type=int, default=0, help="input width when not square (configs[4]: --size 1024 --width 2048)")
