@@ -253,3 +253,27 @@ def transform_pil(img, mask, *, flip: bool, scaled_size, pad, crop_xy, crop_size
         img = img.filter(ImageFilter.GaussianBlur(radius=blur))
     im = np.array(img).astype(np.float32).transpose((2, 0, 1))          # ToTensor :128-133
     return im, np.array(mask).astype(np.float32)
+
+
+def transform_numpy(img: np.ndarray, lab: np.ndarray, *, flip: bool, scaled_size, pad, crop_xy, crop_size: int,
+                    ignore_index: int = 255, blur=None, jitter=None):
+    """The same pipeline as `transform_pil` built only from the restated arithmetic above (no PIL): uint8 [H,W,3] and [H,W]
+    in -> (uint8 [3,Hc,Wc], uint8 [Hc,Wc]).  Checked against tests/golden/input_pipeline.npz (PIL's outputs)."""
+    if flip:
+        img, lab = img[:, ::-1], lab[:, ::-1]
+    for op, factor in (jitter or []):
+        img = jitter_u8(np.ascontiguousarray(img), op, factor)
+    w, h = scaled_size
+    H, W = lab.shape
+    img = resample_u8(np.ascontiguousarray(img), w, h, "bicubic")
+    lab = lab[nearest_table(H, h)][:, nearest_table(W, w)]
+    pw, ph = pad
+    if not (w == crop_size and h == crop_size):
+        if pw or ph:
+            img = np.pad(img, ((ph, ph), (pw, pw), (0, 0)), constant_values=0)
+            lab = np.pad(lab, ((ph, ph), (pw, pw)), constant_values=ignore_index)
+        x1, y1 = crop_xy
+        img, lab = img[y1:y1 + crop_size, x1:x1 + crop_size], lab[y1:y1 + crop_size, x1:x1 + crop_size]
+    if blur is not None and blur != 0:
+        img = gaussian_blur_u8(np.ascontiguousarray(img), blur)
+    return np.ascontiguousarray(img.transpose(2, 0, 1)), np.ascontiguousarray(lab)

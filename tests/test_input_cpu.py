@@ -103,3 +103,4 @@ def test_color_jitter_restatement_equals_pil():
     tri = np.stack([(a >> 16) & 255, (a >> 8) & 255, a & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
     assert np.array_equal(io.rgb2hsv(tri), np.asarray(Image.fromarray(tri).convert("HSV")))
     assert np.array_equal(io.hsv2rgb(tri), np.asarray(Image.fromarray(tri, "HSV").convert("RGB")))
+

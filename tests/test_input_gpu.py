@@ -42,3 +42,4 @@ def test_refuses_cpu_tensors():
     tt = TrainTransform(32)
     with pytest.raises(_lib.MrfpHipError):
         tt(torch.zeros(8, 8, 3, dtype=torch.uint8), torch.zeros(8, 8, dtype=torch.uint8), Draw(False, None, (8, 8), (13, 13), (0, 0), None))
+
