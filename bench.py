@@ -43,7 +43,6 @@ def parse():
     ap.add_argument("--width", type=int, default=0, help="input width when not square (configs[4]: --size 1024 --width 2048)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--backend", default="hip", choices=["hip", "miopen"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay zero_grad + forward + backward as a hipGraph (single GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -99,27 +98,40 @@ def cpu_baseline(args, seconds):
         noise["np1_alpha"] = noise["np1_alpha"].repeat(1, 2, 1, 1)
         noise["np1_beta"] = noise["np1_beta"].repeat(1, 2, 1, 1)
     keys = orc.trainable_keys(sd)
+    mom, it = {}, [0]
 
     def step():
+        """one full train iteration as reference main.py:857-864: forward, backward, SGD(momentum, wd) + poly LR,
+        BatchNorm running-statistics update (oracle.train_steps restated for one iteration)."""
         leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
         work = dict(sd)
         work.update(leaf)
-        loss = orc.mrfp_forward(work, x, y, training=True, toggles=(True, True, True), noise=noise)
-        torch.autograd.grad(loss, [leaf[k] for k in keys])
+        new_stats = {}
+        loss = orc.mrfp_forward(work, x, y, training=True, toggles=(True, True, True), noise=noise, new_stats=new_stats)
+        grads = torch.autograd.grad(loss, [leaf[k] for k in keys])
+        with torch.no_grad():
+            orc.sgd_step({k: sd[k] for k in keys}, dict(zip(keys, grads)), mom,
+                         lr=1e-6 * orc.poly_lr_factor(it[0]), first=(it[0] == 0))     # tiny lr: the timing sample stays finite
+            for k, v in new_stats.items():
+                sd[k].copy_(v)
+        it[0] += 1
     t0 = time.time()
-    step()                                         # warm-up (allocator, oneDNN primitive caches)
-    first = time.time() - t0
-    print("[bench] cpu_baseline: warm-up step %.1f s" % first, file=sys.stderr, flush=True)
+    for _ in range(3):                             # warm-up (allocator, oneDNN primitive caches, momentum buffers)
+        step()
+    print("[bench] cpu_baseline: 3 warm-up steps %.1f s" % (time.time() - t0), file=sys.stderr, flush=True)
     t0, n = time.time(), 0
-    while n < 2 or (time.time() - t0 < seconds and n < 50):
+    while n < 5 or (time.time() - t0 < seconds and n < 50):
         step()
         n += 1
         print("[bench] cpu_baseline: step %d at %.1f s" % (n, time.time() - t0), file=sys.stderr, flush=True)
     dt_ = time.time() - t0
+    width = args.width or args.size
+    scale = (args.size * width) / float(S * S)
     return {"value": round(B * n / dt_, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d train steps (fwd+bwd) of %s MRFP+ at %dx%dx%d fp32 on the CPU oracle; "
-                      "work/image scales with H*W (x%.0f at %dx%d)" % (n, args.trunk, B, S, S,
-                                                                      (args.size / S) ** 2, args.size, args.size)}
+            "per_pixel_scaled_value": round(B * n / dt_ / scale, 4),
+            "sample": "%d train steps (fwd+bwd+SGD, after 3 warm-up steps) of %s MRFP+ at %dx%dx%d fp32 on the CPU oracle; "
+                      "work/image is proportional to H*W, so at the bench size %dx%d (x%.0f pixels) the same host would "
+                      "deliver per_pixel_scaled_value images/sec" % (n, args.trunk, B, S, S, args.size, width, scale)}
 
 
 def main():
@@ -128,12 +140,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("MRFP_FORCE_SYNC") == "1"
+    # MRFP_BENCH_SHARE_GPU=1 + MRFP_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a one-GPU box (every rank on
+    # cuda:0, gloo transport -- RCCL refuses two ranks on one device); tests/test_ddp_gpu.py drives it
+    share = os.environ.get("MRFP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("MRFP_DIST_BACKEND", "nccl")
+    if share:
+        local = 0
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -141,7 +162,6 @@ def main():
     from mrfp_amd import synth, deepv3
     from mrfp_amd.config import cfg
     from mrfp_amd.harness import Trainer
-    cfg.MODEL.CONV_BACKEND = args.backend
     cfg.MODEL.ACT_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
 
     import contextlib
@@ -178,15 +198,15 @@ def main():
         elapsed = tt.item()
     lossv = float(loss.detach())
 
+    # roofline of the dominant kernel family (the MFMA implicit-GEMM convolutions): algorithmic FLOPs of all conv
+    # launches of one step / their summed device time, measured with hipEvents around each launch of ONE EXTRA step.
+    # That step runs on EVERY rank (it issues the gradient all-reduces like any other step: rank 0 alone would leave the
+    # other ranks' collectives unmatched); only rank 0 reports its timings.
+    roof = conv_roofline(model, trainer, x, y, args)
     out = None
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = args.batch * world * args.steps / elapsed
-        # roofline of the dominant kernel family (the MFMA implicit-GEMM convolutions): algorithmic FLOPs of
-        # all conv launches of one step / their summed device time, measured with hipEvents around each launch
-        roof = None
-        if args.backend == "hip":
-            roof = conv_roofline(model, trainer, x, y, args)
         out = {"metric": "train images/sec", "value": round(value, 3), "unit": "images/sec", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -194,7 +214,7 @@ def main():
                                       "%d images/GPU, fwd+bwd+SGD, synthetic 19-class, random-init weights"
                                       % (args.trunk, args.size, width, args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                          "conv_backend": args.backend, "final_loss": round(lossv, 5)},
+                          "final_loss": round(lossv, 5)},
                "roofline": roof}
     if use_dist:
         dist.barrier()
@@ -260,9 +280,31 @@ def conv_roofline(model, trainer, x, y, args):
                        for (n, sh), m, fl in zip(shapes, ms, flops)], f)
     peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # f16 and bf16 MFMA: same dense rate
     ach = tot_f / (tot_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(ms),
+    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(ms),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": None, "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3)}
+    roof.update(measured_traffic(args))
+    return roof
+
+
+def measured_traffic(args):
+    """HBM bytes of the conv kernel family per step from the PMC counters (TCC_EA0_RDREQ / WRREQ passes collected by
+    tools/measure_traffic.sh exactly as MI355X_MICROARCH.md prescribes, in their own rocprofv3 runs) -- read from the
+    committed profiles/r02_traffic.json, which names the commit and the workload it was measured on.  Counters cannot
+    be collected from inside this process, so the figure is attached only when that file describes THIS workload."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    w = t.get("workload", {})
+    if (w.get("trunk"), w.get("size"), w.get("width"), w.get("batch"), w.get("dtype")) != \
+            (args.trunk, args.size, args.width or args.size, args.batch, args.dtype):
+        return {}
+    return {"traffic": t.get("conv_family_hbm_bytes_per_step"), "traffic_unit": "bytes/step (conv kernel family, PMC)",
+            "traffic_algorithmic": t.get("conv_family_algorithmic_bytes_per_step"),
+            "traffic_measured_at_commit": t.get("commit"), "traffic_source": "profiles/r02_traffic.json"}
 
 
 if __name__ == "__main__":

@@ -41,10 +41,12 @@ def _compile(src):
     return obj
 
 
-def build(force: bool = False) -> str:
+def build(force: bool = False, always=()) -> str:
+    """force: recompile everything.  always: translation units that are recompiled (and the library relinked) even if
+    their object file looks current."""
     srcs = _sources()
-    if force:
-        for s in srcs:
+    for s in srcs:
+        if force or s in always:
             o = os.path.join(CSRC, s[:-4] + ".o")
             if os.path.exists(o):
                 os.remove(o)

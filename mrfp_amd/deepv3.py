@@ -31,8 +31,14 @@ __all__ = ["_AtrousSpatialPyramidPoolingModule", "MRFPPlus", "simpleDeepV3Plus",
 class ReferenceRandom:
     """The reference's three RNG uses inside forward (deepv3.py:281-283, 290-306, 274-275)."""
 
+    _py = random        # python's global stream, as the reference; harness.sync_replicas() installs a shared private one
+
     def toggles(self):
-        return random.random(), random.random(), random.random()
+        return self._py.random(), self._py.random(), self._py.random()
+
+    def seed_toggles(self, seed):
+        """Private toggle stream (same seed on every rank of a data-parallel job: all ranks take the same branches)."""
+        self._py = random.Random(seed)
 
     def reinit_hrfp(self, model):
         for conv, bn in model.hrfp_layers():
@@ -179,6 +185,12 @@ class _DeepLabBase(nn.Module):
         self.whitening = False
         self.three_input_layer = False
 
+    _taps = None        # tests set this to a dict: per-stage activations are recorded there (names as the oracle's taps)
+
+    def _tap(self, name, t):
+        if self._taps is not None:
+            self._taps[name] = t.detach()
+
     def _stem(self, x):
         """layer0: conv(s) -> norm -> ReLU -> maxpool (reference deepv3.py:309-315)."""
         trunk = self._trunk[0]
@@ -200,7 +212,11 @@ class _DeepLabBase(nn.Module):
     def _high(self, t, w_arr):
         """low-level features -> ASPP input: layer2..layer4 (reference deepv3.py:338-344) / mod4..mod7 + bn_out."""
         if hasattr(self, "layer1"):
-            return self.layer4(self.layer3(self.layer2([t, w_arr])))[0]
+            t = self.layer2([t, w_arr])
+            self._tap("layer2", t[0])
+            t = self.layer3(t)
+            self._tap("layer3", t[0])
+            return self.layer4(t)[0]
         t = self.mod7(self.mod6(self.mod5(self.mod4(t))))
         return self.bn_out[0].fused(t, relu=True)
 
@@ -219,10 +235,9 @@ class _DeepLabBase(nn.Module):
         full-resolution logits are never written."""
         f2 = self.final2[0]
         nc = f2.out_channels
-        hip = cfg.MODEL.CONV_BACKEND == "hip"
-        pitch = (nc + 31) // 32 * 32 if hip else None
+        pitch = (nc + 31) // 32 * 32
         dec2 = ops.conv2d(dec1, f2.weight, f2.bias, f2.stride, f2.padding, f2.dilation, phys_out=pitch)
-        if training and hip and cfg.MODEL.FUSE_UPSAMPLE_CE and self._plain_ce():
+        if training and cfg.MODEL.FUSE_UPSAMPLE_CE and self._plain_ce():
             return ops.upsample_cross_entropy(dec2, gts, size, nc, self.criterion.ignore_index)
         main_out = ops.upsample_bilinear(dec2, size, channels=nc)
         if training:
@@ -314,6 +329,7 @@ class MRFPPlus(_DeepLabBase):
                 t = conv(t)
             plan = ops.nearest_plan(t.shape[2], t.shape[3], device=t.device, **rs)
             t = bn.fused(t, relu=True, plan=plan)
+            self._tap("hrfp%d" % i, t)
         return dec, t, xp_alias
 
     def forward(self, x, gts=None, training=True):
@@ -326,22 +342,29 @@ class MRFPPlus(_DeepLabBase):
         xp, w_arr = self._stem(x)
         if training == True and self.fourier_perturb is not None:      # noqa: E712  (extension, default off)
             xp = self.fourier_perturb(xp)
+        self._tap("stem", xp)
         OCout_dec, OCout, xp = self._hrfp(xp, h, w)   # always computed, as the reference does (no RNG inside)
         t = xp
         if npp:
             t = self.Normalization_Perturbation_Plus(xp, "np1")
+            self._tap("np1", t)
         if o1:
             t = ops.add(OCout, t)
         t = self._low(t, w_arr)
         if npp:
             t = self.Normalization_Perturbation_Plus(t, "np2")
+        self._tap("layer1", t)
         dec0_fine, low_level = self.bot_fine.forward_skip(t)      # low-level features: decoder + layer2
-        t = self.aspp(self._high(low_level, w_arr))
+        t = self._high(low_level, w_arr)
+        self._tap("layer4", t)
+        t = self.aspp(t)
+        self._tap("aspp", t)
         dec0_up = self.bot_aspp(t)
         dec0_up = Upsample(dec0_up, low_level.shape[2:])
         dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))
+        self._tap("dec1", dec1)
         if o2:                                         # "+" of MRFP+: deepv3.py:355-357
-            if cfg.MODEL.CONV_BACKEND == "hip" and cfg.MODEL.COMMUTE_O2:
+            if cfg.MODEL.COMMUTE_O2:
                 return self._head_o2(dec1, OCout_dec, (h, w), gts, training)
             dec1 = ops.upsample_bilinear(dec1, (int(h / 2), int(w / 2)), addend=OCout_dec)   # one fused pass
         return self._head(dec1, (h, w), gts, training)

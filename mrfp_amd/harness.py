@@ -34,9 +34,14 @@ class FlatArena:
     16-byte aligned).  Device-agnostic host logic: the data-parallel buckets are ranges of `flat_g`."""
 
     def __init__(self, model: torch.nn.Module):
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        every = list(model.parameters())
+        self.params = [p for p in every if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        # the reference hands model.parameters() -- frozen HRFP tensors included -- to torch.optim.SGD (main.py:826), so
+        # its optimizer.state_dict() numbers parameters by their position in THAT list
+        self.n_all = len(every)
+        self.all_index = [i for i, p in enumerate(every) if p.requires_grad]
         dev = self.params[0].device
         self.offsets, n = [], 0
         for p in self.params:
@@ -64,20 +69,63 @@ class FlatSGD(FlatArena):
 
     def __init__(self, model: torch.nn.Module, lr=1e-2, momentum=0.9, weight_decay=5e-4, max_iter=40000, power=0.9):
         super().__init__(model)
-        if self.flat_p.device.type != "cuda":
-            raise _lib.MrfpHipError("FlatSGD needs the model on the GPU: the HIP path has no CPU fallback")
         self.flat_m = torch.zeros_like(self.flat_p)
         self.base_lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.max_iter, self.power = max_iter, power
         self.it = 0
+        self.has_momentum = False        # torch.optim.SGD: the first step copies the gradient into the momentum buffer
 
     @property
     def lr(self):
         return self.base_lr * poly_lr_factor(self.it, self.max_iter, self.power)
 
+    # ---- checkpoint ABI: the layout of torch.optim.SGD.state_dict() (reference main.py:867 stores it as 'optimizer') ----
+    def state_dict(self):
+        """torch.optim.SGD.state_dict() of the reference's optimizer after the same number of steps: one param group
+        over ALL model parameters (frozen ones have no state entry), per-parameter `momentum_buffer` cut from the
+        momentum arena, `lr` = current scheduled rate, `initial_lr` = base rate (LambdaLR adds it).  The extra key
+        `mrfp_iteration` carries the scheduler position, which the reference does not save (its resume restarts the
+        poly schedule); loading a plain torch state dict recovers it from lr / initial_lr."""
+        state = {}
+        if self.has_momentum:
+            for i, p, o in zip(self.all_index, self.params, self.offsets):
+                state[i] = {"momentum_buffer": self.flat_m[o:o + p.numel()].view(p.shape).detach().clone().cpu()}
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay,
+                 "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "initial_lr": self.base_lr, "params": list(range(self.n_all))}
+        return {"state": state, "param_groups": [group], "mrfp_iteration": self.it}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        self.momentum, self.weight_decay = float(group["momentum"]), float(group["weight_decay"])
+        self.base_lr = float(group.get("initial_lr", group["lr"]))
+        if "mrfp_iteration" in sd:
+            self.it = int(sd["mrfp_iteration"])
+        else:                                   # a checkpoint written by torch.optim.SGD + LambdaLR: invert the poly factor
+            f = float(group["lr"]) / self.base_lr if self.base_lr > 0 else 1.0
+            self.it = int(round(self.max_iter * (1.0 - min(max(f, 0.0), 1.0) ** (1.0 / self.power))))
+        state = sd.get("state", {})
+        pos = {idx: j for j, idx in enumerate(group["params"])}     # saved id -> position in model.parameters()
+        self.flat_m.zero_()
+        n = 0
+        for key, st in state.items():
+            j = pos.get(key, pos.get(int(key)) if not isinstance(key, int) else None)
+            if j is None or j not in self.all_index or st.get("momentum_buffer") is None:
+                continue
+            t = self.all_index.index(j)
+            p, o = self.params[t], self.offsets[t]
+            self.flat_m[o:o + p.numel()].copy_(st["momentum_buffer"].reshape(-1).to(self.flat_m.device, torch.float32))
+            n += 1
+        if 0 < n < len(self.params):
+            raise _lib.MrfpHipError("optimizer state covers %d of %d trainable tensors" % (n, len(self.params)))
+        self.has_momentum = n > 0
+
     def step(self, gscale: float = 1.0):
+        if self.flat_p.device.type != "cuda":
+            raise _lib.MrfpHipError("FlatSGD.step needs the arenas on the GPU: the HIP path has no CPU fallback")
         call("mrfp_sgd_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), self.n, float(self.lr),
-             float(self.momentum), float(self.weight_decay), float(gscale), int(self.it == 0), stream())
+             float(self.momentum), float(self.weight_decay), float(gscale), int(not self.has_momentum), stream())
+        self.has_momentum = True
         # the fused kernel wrote the arena behind autograd's version counters: invalidate the derived
         # weight packs explicitly (mrfp_amd/conv.py rebuilds them on next use)
         from . import conv
@@ -113,6 +161,7 @@ class GradSync:
                 self.bucket_of[i] = b
         self.pending = [0] * len(self.buckets)
         self.seen = [False] * len(opt.params)
+        self.next = 0                    # buckets are launched strictly in index order on every rank
         self.works = []
         self.on_gpu = opt.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None
@@ -135,11 +184,18 @@ class GradSync:
             if self.seen[i]:
                 return
             self.seen[i] = True
-            b = self.bucket_of[i]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                self._launch(b)
+            self.pending[self.bucket_of[i]] -= 1
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Collectives must be issued in the same order on every rank, whatever order the gradients arrive in (ranks
+        may draw different perturbation toggles, a tensor may get no gradient on one rank): a bucket is launched only
+        when every bucket before it has been launched -- bucket 0 holds the LAST parameters, whose gradients arrive
+        first, so in the common case this is still "as soon as the bucket is complete"."""
+        while self.next < len(self.buckets) and self.pending[self.next] == 0:
+            self._launch(self.next)
+            self.next += 1
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
@@ -158,6 +214,7 @@ class GradSync:
         if self.enabled:
             self.pending = [len(m) for _, _, m in self.buckets]
             self.seen = [False] * len(self.opt.params)
+            self.next = 0
             self.works = []
 
     def finish(self):
@@ -166,15 +223,39 @@ class GradSync:
         conv.join_wgrad_stream()                     # weight gradients are computed on a second stream (mrfp_amd/conv.py)
         if not self.enabled:
             return 1.0
-        for b, n in enumerate(self.pending):        # buckets whose tensors got no gradient this step
-            if n > 0:
-                self.pending[b] = 0
-                self._launch(b)
+        for b in range(self.next, len(self.buckets)):   # buckets with tensors that got no gradient this step: same order
+            self.pending[b] = 0
+        self._launch_ready()
         for w in self.works:
             w.wait()
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.side)
         return 1.0 / self.world
+
+
+def sync_replicas(model, arena: Optional[FlatArena] = None, group=None, src: int = 0):
+    """What DistributedDataParallel does at construction: every rank starts from rank `src`'s parameters and buffers
+    (MRFPPlus.__init__ draws its initial weights from the unseeded global RNG, and a missing pretrained checkpoint keeps
+    them: without this, replicas would differ for ever because only gradients are averaged).  Also makes the three
+    perturbation toggles of MRFPPlus.forward agree across ranks for the whole run: the reference seeds python's
+    `random` identically everywhere (main.py:38); here rank `src` draws one seed and every rank gets a private
+    `random.Random(seed)` for the toggles -- no per-step collective, no host synchronisation."""
+    if arena is not None:
+        dist.broadcast(arena.flat_p, src, group=group)
+    with torch.no_grad():
+        for p in model.parameters():
+            if arena is None or not p.requires_grad:
+                dist.broadcast(p.data, src, group=group)
+        for b in model.buffers():
+            dist.broadcast(b.data, src, group=group)
+    from . import conv
+    conv.invalidate_packs()
+    rng = getattr(model, "rng", None)
+    if rng is not None and hasattr(rng, "seed_toggles"):
+        import random
+        seed = [random.getrandbits(62) if dist.get_rank(group) == src else 0]
+        dist.broadcast_object_list(seed, src, group=group)
+        rng.seed_toggles(seed[0])
 
 
 class Trainer:
@@ -190,6 +271,8 @@ class Trainer:
         self.model = model
         self.opt = FlatSGD(model, lr, momentum, weight_decay, max_iter)
         self.sync = GradSync(self.opt, bucket_mb)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            sync_replicas(model, self.opt)
         if loss_scale is None:
             loss_scale = 65536.0 if cfg.MODEL.ACT_DTYPE == torch.float16 else 1.0
         self.loss_scale = float(loss_scale)
@@ -291,7 +374,10 @@ def evaluate(model, batches, num_classes=19):
             continue
         logits = model(img, training=False)
         hist, _ = ops.argmax_hist(logits, label, hist)
-    if hist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if hist is None:                              # this rank dropped all of its batches: still take part
+            dev = next(model.parameters()).device
+            hist = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=dev)
         dist.all_reduce(hist)
     h = hist.cpu().numpy() if hist is not None else None
     return h, (metrics.miou_from_hist(h) if h is not None else 0.0), dropped
@@ -300,22 +386,29 @@ def evaluate(model, batches, num_classes=19):
 # ------------------------------------------------------------------------------------------
 # checkpoints in the reference's format (reference main.py:867-869, 884-886)
 # ------------------------------------------------------------------------------------------
-def save_checkpoint(path, model, epoch, optimizer_state=None):
-    """{'epoch', 'state_dict', ['optimizer']} with the `module.` prefix nn.DataParallel gives the keys."""
+def save_checkpoint(path, model, epoch, optimizer=None):
+    """{'epoch', 'state_dict', 'optimizer'} as reference main.py:867-869 writes it, with the `module.` prefix
+    nn.DataParallel gives the keys.  `optimizer`: a FlatSGD / Trainer (its torch.optim.SGD-layout state_dict() is
+    stored), a torch optimizer, or an already-built state dict."""
     sd = {"module." + k: v.detach().cpu() for k, v in model.state_dict().items()}
     ck = {"epoch": epoch, "state_dict": sd}
-    if optimizer_state is not None:
-        ck["optimizer"] = optimizer_state
+    if optimizer is not None:
+        opt = getattr(optimizer, "opt", optimizer)                  # Trainer -> its FlatSGD
+        ck["optimizer"] = opt.state_dict() if hasattr(opt, "state_dict") else opt
     torch.save(ck, path)
 
 
-def load_checkpoint(path_or_dict, model, strict=True):
-    """Loads a reference checkpoint (keys with or without the `module.` prefix) into the HIP model."""
-    ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, str) else path_or_dict
+def load_checkpoint(path_or_dict, model, strict=True, optimizer=None):
+    """Loads a reference checkpoint (keys with or without the `module.` prefix) into the HIP model and, when
+    `optimizer` (FlatSGD / Trainer) is given and the checkpoint has an 'optimizer' entry, the momentum buffers and the
+    schedule position (reference main.py:884-886 + the 'optimizer' entry of main.py:867)."""
+    ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if isinstance(path_or_dict, str) else path_or_dict
     sd = ck["state_dict"] if "state_dict" in ck else ck
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
     with torch.no_grad():
         missing = model.load_state_dict(sd, strict=strict)
     from . import conv
     conv.invalidate_packs()
+    if optimizer is not None and isinstance(ck, dict) and ck.get("optimizer") is not None:
+        getattr(optimizer, "opt", optimizer).load_state_dict(ck["optimizer"])
     return ck.get("epoch", None) if isinstance(ck, dict) else None, missing

@@ -648,37 +648,23 @@ def as_activation(x: torch.Tensor) -> torch.Tensor:
     from .config import cfg
     if not x.is_cuda:
         raise _lib.MrfpHipError("input must live on the GPU (got %s): the HIP path has no CPU fallback" % x.device)
-    if cfg.MODEL.CONV_BACKEND == "hip":     # one kernel: NCHW fp32 -> NHWC act dtype, channels padded to a chunk
-        from . import conv
-        return conv.pad_input_channels(x, cfg.MODEL.ACT_DTYPE)
-    if x.dtype != cfg.MODEL.ACT_DTYPE:
-        x = x.to(cfg.MODEL.ACT_DTYPE)
-    return to_cl(x)
+    from . import conv                      # one kernel: NCHW fp32 -> NHWC act dtype, channels padded to a chunk
+    return conv.pad_input_channels(x, cfg.MODEL.ACT_DTYPE)
 
 
 def conv2d_skip(x, weight, bias, stride, padding, dilation):
-    """(conv(x), alias of x for a skip connection): with the HIP backend the skip gradient is accumulated in the
-    dgrad epilogue; with the stock backend the alias is x itself."""
-    from .config import cfg
-    x = _chk(x)
-    if cfg.MODEL.CONV_BACKEND == "hip":
-        from . import conv
-        return conv.conv2d(x, weight, bias, stride, padding, dilation, None, True)
-    return conv2d(x, weight, bias, stride, padding, dilation), x
+    """(conv(x), alias of x for a skip connection): the gradient arriving on the alias is accumulated in this conv's
+    dgrad epilogue."""
+    from . import conv
+    return conv.conv2d(_chk(x), weight, bias, stride, padding, dilation, None, True)
 
 
 def conv2d(x, weight, bias, stride, padding, dilation, phys_out=None):
-    """nn.Conv2d forward/backward.  Backend 'hip': MFMA implicit-GEMM kernels (mrfp_amd/conv.py);
-    backend 'miopen': stock ROCm convolution through ATen on the same NHWC tensors (BASELINE.json
-    configs[1] "stock ROCm convs").  phys_out (hip only): return the channel-padded output buffer."""
-    from .config import cfg
-    x = _chk(x)
-    if cfg.MODEL.CONV_BACKEND == "hip":
-        from . import conv
-        return conv.conv2d(x, weight, bias, stride, padding, dilation, phys_out)
-    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
-    b = bias if bias is None or bias.dtype == x.dtype else bias.to(x.dtype)
-    return torch.nn.functional.conv2d(x, w.contiguous(memory_format=CL), b, stride, padding, dilation)
+    """nn.Conv2d forward/backward on the MFMA implicit-GEMM kernels (mrfp_amd/conv.py).  phys_out: return the
+    channel-padded output buffer.  There is no other backend: a stock-ROCm (MIOpen) comparison of BASELINE.json
+    configs[1] was measured once in round 1 and does not live in the product."""
+    from . import conv
+    return conv.conv2d(_chk(x), weight, bias, stride, padding, dilation, phys_out)
 
 
 class _ConcatChannels(torch.autograd.Function):

@@ -44,9 +44,21 @@ def synth_tensor(key: str, shape: Tuple[int, ...], seed: int = 0, dtype=torch.fl
     return torch.randn(shape, generator=g) * 0.1
 
 
-def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
-    """spec: iterable of (key, shape) in state_dict order."""
-    return OrderedDict((k, synth_tensor(k, tuple(s), seed)) for k, s in spec)
+def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0,
+                     residual_gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+    """spec: iterable of (key, shape) in state_dict order.
+
+    residual_gain scales the weight of the LAST BatchNorm of every bottleneck (`*.bn3.weight`).  With the default 1.0
+    every residual branch is as strong as its skip path and the trunk amplifies fp32 rounding noise 3-4x per stage
+    (the reference's own fp32 logits are then 0.8e-3 .. 1.5e-3 away from an fp64 evaluation, at any batch size:
+    tests/golden/make_golden_wc.py prints it); 0.3 is the regime of a trained / zero-init-residual network (noise
+    5e-5 .. 8e-5) and is what the well-conditioned fixtures (mrfp_wc.npz, r101.npz) use."""
+    sd = OrderedDict((k, synth_tensor(k, tuple(s), seed)) for k, s in spec)
+    if residual_gain != 1.0:
+        for k in sd:
+            if k.endswith("bn3.weight"):
+                sd[k] = sd[k] * residual_gain
+    return sd
 
 
 def spec_of(state_dict: Dict[str, torch.Tensor]):

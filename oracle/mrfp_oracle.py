@@ -262,6 +262,41 @@ def wider_resnet_a2(sd, img: Tensor, train: bool, new_stats=None, drop_masks=Non
     return F.relu(batch_norm(sd, "bn_out.0", t, train, new_stats))
 
 
+def _resnet_stem(sd, x, norm):
+    """Stem of the two ResNet trunks up to (not including) the max-pool, keys in the `layer0.N` form MRFPPlus gives
+    them.  `layer0.3.weight` present = deep stem of ResNet3X3 (reference Resnet.py:344-435, 475-496: three 3x3 convs,
+    64/64/128 channels, norms selected by wt_layer[0..2]); otherwise conv7x7 s2 -> norm -> ReLU of ResNet (reference
+    Resnet.py:523-549, deepv3.py:309-313)."""
+    if "layer0.3.weight" in sd:
+        t = F.relu(norm("layer0.1", conv(sd, "layer0.0", x, stride=2, padding=1)))
+        t = F.relu(norm("layer0.4", conv(sd, "layer0.3", t, padding=1)))
+        return F.relu(norm("layer0.7", conv(sd, "layer0.6", t, padding=1)))
+    return F.relu(norm("layer0.1", conv(sd, "layer0.0", x, stride=2, padding=3)))
+
+
+def resnet_trunk(sd, x: Tensor, train: bool, new_stats=None, d16: bool = False, taps: Optional[dict] = None) -> Tensor:
+    """ResNet.forward / ResNet3X3.forward without the classifier (reference Resnet.py:475-512, 587-615), state-dict keys
+    in MRFPPlus's `layer0.N` form.  d16=True applies the dilation surgery of reference deepv3.py:184-189 to layer4.
+    This is the function tests/golden/make_golden_r101.py pins against the reference's resnet101 (ResNet3X3)."""
+    def norm(key, v):
+        if key + ".running_mean" in sd:
+            return batch_norm(sd, key, v, train, new_stats)
+        return instance_norm(sd, key, v)
+    t = F.max_pool2d(_resnet_stem(sd, x, norm), 3, 2, 1)
+    if taps is not None:
+        taps["stem"] = t
+    for (name, planes, _, stride) in R50_STAGES:
+        nblk = sum(1 for k in sd if k.startswith(name + ".") and k.endswith(".conv1.weight"))
+        iw = 4 if "%s.%d.instance_norm_layer.weight" % (name, nblk - 1) in sd else 0
+        if name == "layer4" and d16:
+            t = _stage(sd, name, planes, nblk, 1, 2, t, iw, train, new_stats)
+        else:
+            t = _stage(sd, name, planes, nblk, stride, 1, t, iw, train, new_stats)
+        if taps is not None:
+            taps[name] = t
+    return t
+
+
 def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None, *,
                  training: bool = True, bn_train: Optional[bool] = None,
                  toggles: Tuple[bool, bool, bool] = (True, True, True),
@@ -294,16 +329,8 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
         # the trunk arithmetic itself is pinned by tests/golden/wrn38.npz): stem = mod1 -> pool2 -> mod2 -> pool3
         t = conv(sd, "mod1.conv1", x, padding=1)
         t = _wrn_module(sd, "mod2", F.max_pool2d(t, 3, 2, 1), bn_train, new_stats, noise)
-    elif "layer0.3.weight" in sd:
-        # deep stem of ResNet3X3 (reference Resnet.py:350-435, 475-496): three 3x3 convs; layer0 =
-        # Sequential(conv1,bn1,relu1,conv2,bn2,relu2,conv3,bn3,relu3,maxpool) -- a build-defined composition
-        # for trunk='resnet-101' (the reference's MRFPPlus only accepts resnet-50)
-        t = F.relu(norm("layer0.1", conv(sd, "layer0.0", x, stride=2, padding=1)))
-        t = F.relu(norm("layer0.4", conv(sd, "layer0.3", t, padding=1)))
-        t = F.relu(norm("layer0.7", conv(sd, "layer0.6", t, padding=1)))
     else:
-        # stem: conv7x7 s2 -> InstanceNorm(affine) -> ReLU -> maxpool3x3 s2 (deepv3.py:309-315)
-        t = F.relu(norm("layer0.1", conv(sd, "layer0.0", x, stride=2, padding=3)))
+        t = _resnet_stem(sd, x, norm)
     t = F.max_pool2d(t, 3, 2, 1)
     xp = t
     taps["stem"] = xp

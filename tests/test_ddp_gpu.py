@@ -41,7 +41,7 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from mrfp_amd.harness import Trainer
-    model = _Wrap(_build(0))
+    model = _Wrap(_build(rank))             # DIFFERENT initial weights per rank: Trainer must broadcast rank 0's
     tr = Trainer(model, lr=1e-3, bucket_mb=4.0)
     assert tr.sync.enabled and len(tr.sync.buckets) >= 3
     g = torch.Generator().manual_seed(100 + rank)
@@ -86,3 +86,117 @@ def test_two_rank_gradient_sync_on_gpu(tmp_path):
         ref += arena.flat_g / world
     torch.cuda.synchronize()
     torch.testing.assert_close(g[0][0], ref.cpu(), rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL itself: one rank, backend nccl, MRFP_FORCE_SYNC=1 -> buckets, side stream, wgrad stream join and the RCCL
+# all-reduce kernels all run; the result must equal the plain single-process step bit for bit (a 1-rank sum is x).
+# ---------------------------------------------------------------------------------------------------------------------
+def _worker_nccl(outdir, force):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if force:
+        os.environ["MRFP_FORCE_SYNC"] = "1"
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sys.path.insert(0, ROOT)
+    from mrfp_amd.harness import Trainer
+    model = _Wrap(_build(0))
+    tr = Trainer(model, lr=1e-3, bucket_mb=4.0)
+    assert tr.sync.enabled == bool(force)
+    g = torch.Generator().manual_seed(100)
+    x = (torch.rand(2, 3, 64, 64, generator=g) * 255).cuda()
+    losses = [float(tr.step(x, None)) for _ in range(3)]
+    torch.cuda.synchronize()
+    torch.save((tr.opt.flat_p.cpu(), losses, len(tr.sync.buckets)), os.path.join(outdir, "n%d.pt" % int(force)))
+    if force:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_forced_sync_equals_plain_step(tmp_path):
+    ctx = mp.get_context("spawn")
+    for force in (0, 1):
+        p = ctx.Process(target=_worker_nccl, args=(str(tmp_path), force))
+        p.start()
+        p.join(timeout=600)
+        assert p.exitcode == 0, force
+    plain = torch.load(os.path.join(str(tmp_path), "n0.pt"))
+    rccl = torch.load(os.path.join(str(tmp_path), "n1.pt"))
+    assert rccl[2] >= 3                                        # several buckets went through RCCL
+    assert plain[1] == rccl[1] and torch.equal(plain[0], rccl[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cross-rank switchable whitening (iw = 5) against the reference's SyncSwitchWhiten2d run by two gloo processes
+# (tests/golden/syncsw.npz, tests/golden/make_golden_syncsw.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _worker_syncsw(rank, world, port, outdir):
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_syncsw as gen                      # seeds / parameter values only (no reference import at module level)
+    from mrfp_amd.network.sync_switchwhiten import SyncSwitchWhiten2d
+    sw = SyncSwitchWhiten2d(gen.C, num_pergroup=16, sw_type=2, T=5, tie_weight=False, eps=1e-5, momentum=0.99, affine=True).cuda()
+    with torch.no_grad():
+        for k, v in gen.params().items():
+            getattr(sw, k).copy_(v)
+    sw.train()
+    x, gy = gen.case(rank)
+    x = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = sw(x)
+    y.backward(gy.cuda().contiguous(memory_format=torch.channels_last))
+    out = {"y": y, "gx": x.grad, "g_weight": sw.weight.grad, "g_bias": sw.bias.grad, "g_mean_w": sw.sw_mean_weight.grad,
+           "g_var_w": sw.sw_var_weight.grad, "running_mean": sw.running_mean, "running_cov": sw.running_cov}
+    sw.eval()
+    with torch.no_grad():
+        out["y_eval"] = sw(x.detach())
+    np.savez(os.path.join(outdir, "s%d.npz" % rank), **{k: v.detach().float().cpu().numpy() for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_switch_whiten_two_ranks_vs_reference(tmp_path):
+    import numpy as np
+    G = np.load(os.path.join(ROOT, "tests", "golden", "syncsw.npz"))
+    world, port = 2, 29747
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_syncsw, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    tol = {"y": 2e-4, "y_eval": 2e-4, "gx": 2e-3, "g_weight": 2e-3, "g_bias": 2e-4, "g_mean_w": 5e-3, "g_var_w": 5e-3,
+           "running_mean": 1e-4, "running_cov": 1e-4}
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "s%d.npz" % r))
+        for k, t in tol.items():
+            assert rel(z[k], G["r%d_%s" % (r, k)]) < t, (r, k, rel(z[k], G["r%d_%s" % (r, k)]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py end to end at world size 2 (the roofline leg used to run on rank 0 only and would have left the
+# other ranks' collectives unmatched).  Both ranks share the one GPU, gloo transport.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_bench_two_ranks_end_to_end():
+    import json
+    import subprocess
+    env = dict(os.environ, MRFP_BENCH_SHARE_GPU="1", MRFP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29753", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--trunk", "resnet-50", "--size", "128", "--batch", "2", "--dtype", "bf16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                      # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["cpu_baseline"] is None

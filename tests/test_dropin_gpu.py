@@ -1,0 +1,100 @@
+"""The literal drop-in: the call sequence of the reference's main.py run against the HIP modules with nothing but
+`mrfp_amd/dropin` in front on sys.path --
+
+    from deepv3 import *                                                        (main.py:31)
+    model = nn.DataParallel(MRFPPlus(num_classes=19, criterion=criterion).to('cuda:0'), device_ids=[0])   (main.py:824)
+    optimizer = torch.optim.SGD(model.parameters(), lr=..., momentum=0.9, weight_decay=5e-4)              (main.py:826)
+    scheduler = LambdaLR(optimizer, lr_lambda=LRPolicy(...))                                              (main.py:832-839)
+    loss = model(img, label.long(), training=True); optimizer.zero_grad(); loss.backward(); optimizer.step();
+    scheduler.step(); "{:.4f}".format(loss)                                                               (main.py:857-866)
+    torch.save({'epoch', 'state_dict', 'optimizer'})                                                      (main.py:867-869)
+    model.eval(); outputs = model(img, training=False); outputs.data.cpu().numpy()                        (main.py:887-899)
+    metrics.fast_hist / evaluate_eval arithmetic                                                          (main.py:900-913)
+
+and checked against the reference's own numbers (tests/golden/mrfp_c1.npz: the three-step lr 1e-4 trajectory the
+reference produced with torch.optim.SGD + LambdaLR, its eval histogram and mIoU) and against the fused Trainer.
+Runs in a subprocess so that the bare module names (`deepv3`, `config`, `network`, `metrics`) do not leak into the test
+session."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import json, math, os, sys
+ROOT = sys.argv[1]
+sys.path.insert(0, os.path.join(ROOT, "mrfp_amd", "dropin"))
+sys.path.insert(1, ROOT)
+import numpy as np
+import torch
+import torch.nn as nn
+from deepv3 import *                      # main.py:31
+import deepv3 as _d
+assert _d.__file__.startswith(os.path.join(ROOT, "mrfp_amd", "dropin")), _d.__file__
+from mrfp_amd import synth
+from mrfp_amd.deepv3 import InjectedRandom
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "mrfp_c1.npz"))
+SPEC = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_spec.json")))
+criterion = nn.CrossEntropyLoss(ignore_index=255)                                                  # main.py:822
+model = nn.DataParallel(MRFPPlus(num_classes=19, criterion=criterion).to('cuda:0'), device_ids=[0])  # main.py:824
+sd0 = synth.synth_state_dict([(k, tuple(s)) for k, s in SPEC["MRFPPlus"]], seed=0)
+model.load_state_dict({"module." + k: v for k, v in sd0.items()})                                   # main.py:886 layout
+optimizer = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)          # main.py:826
+class LRPolicy(object):                                                                             # main.py:832-837
+    def __init__(self, powr, max_iter): self.powr, self.max_iter = powr, max_iter
+    def __call__(self, iter): return math.pow(1 - iter / self.max_iter, self.powr)
+scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=LRPolicy(0.9, 40000))            # main.py:839
+
+toggles = [(True, True, True), (False, True, False), (True, False, True)]
+model.train()                                                                                       # main.py:847
+losses, shown = [], []
+for i in range(3):
+    img, label = synth.synth_batch(2, 256, 256, seed=10 + i)
+    model.module.rng = InjectedRandom(toggles[i], synth.synth_noise(2, seed=20 + i))
+    img, label = img.to('cuda:0'), label.to('cuda:0')
+    loss = model(img, label.long(), training=True)                                                  # main.py:860
+    optimizer.zero_grad(); loss.backward(); optimizer.step(); scheduler.step()                      # main.py:861-864
+    shown.append("{:.4f}".format(loss))                                                             # main.py:866
+    losses.append(float(loss))
+ck = os.path.join(sys.argv[2], "ck.pth")
+torch.save({'epoch': 1, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}, ck)  # main.py:867-869
+
+model.load_state_dict({"module." + k: v for k, v in sd0.items()})
+model.eval()                                                                                        # main.py:887
+x, y = synth.synth_batch(2, 256, 256, seed=1)
+with torch.no_grad():
+    outputs = model(x.to('cuda:0'), training=False)                                                 # main.py:896
+pred = outputs.data.cpu().numpy()                                                                   # main.py:898-899
+pred = np.argmax(pred, axis=1)
+import metrics
+target = y.numpy().astype('int64')                                                                   # main.py:905
+hist = metrics.fast_hist(pred.flatten(), target.flatten(), 19)                                       # main.py:909
+miou = metrics.evaluate_eval(hist, dataset_name='synthetic')["mean_iu"]                              # main.py:913 (prints)
+keys = list(torch.load(ck, weights_only=False)["state_dict"].keys())
+print("RESULT " + json.dumps({"losses": losses, "shown": shown, "ref": G["train3lo_losses"].tolist(),
+                               "hist_diff": int(np.abs(hist - G["eval_hist"]).sum()), "hist_sum": int(hist.sum()),
+                               "miou": float(miou), "miou_ref": float(G["eval_miou"]), "n_keys": len(keys),
+                               "prefixed": all(k.startswith("module.") for k in keys),
+                               "opt_state": len(torch.load(ck, weights_only=False)["optimizer"]["state"]),
+                               "shape": list(outputs.shape), "dtype": str(outputs.dtype)}))
+'''
+
+
+def test_main_py_call_sequence_through_dropin(tmp_path):
+    r = subprocess.run([sys.executable, "-c", SCRIPT, ROOT, str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    out = json.loads(line[len("RESULT "):])
+    for got, ref in zip(out["losses"], out["ref"]):                 # the reference's own SGD trajectory (lr 1e-4 pin)
+        assert abs(got - ref) / ref < 1e-3, (out["losses"], out["ref"])
+    assert all(len(s.split(".")[1]) == 4 for s in out["shown"])
+    assert out["shape"] == [2, 19, 256, 256] and out["dtype"] == "torch.float32"
+    assert out["hist_diff"] <= 0.002 * out["hist_sum"]
+    assert abs(100 * out["miou"] - 100 * out["miou_ref"]) < 0.1
+    assert out["n_keys"] == 431 and out["prefixed"] and out["opt_state"] == 192

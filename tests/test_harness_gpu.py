@@ -132,7 +132,7 @@ def test_eval_harness_hist_miou_and_checkpoint_roundtrip(tmp_path):
     assert abs(100 * miou - 100 * float(G["eval_miou"])) < 0.1
     path = str(tmp_path / "ck.pth")
     harness.save_checkpoint(path, model, epoch=3)
-    ck = torch.load(path)
+    ck = torch.load(path, weights_only=False)
     assert set(ck) == {"epoch", "state_dict"} and all(k.startswith("module.") for k in ck["state_dict"])
     assert len(ck["state_dict"]) == 431
     from mrfp_amd import deepv3
@@ -199,3 +199,53 @@ def test_training_reduces_the_loss(dtype):
         cfg.MODEL.ACT_DTYPE = torch.float32
     assert all(np.isfinite(losses)), losses
     assert min(losses[-5:]) < 0.6 * losses[0], losses
+
+
+def test_resume_from_checkpoint_reproduces_step_4_bit_for_bit(tmp_path):
+    """reference main.py:867-869 / 884-886: {'epoch', 'state_dict', 'optimizer'}.  3 steps -> save -> fresh process
+    state (new model, new Trainer) -> load -> step 4 must equal step 4 of the uninterrupted run BIT FOR BIT (weights,
+    BN running statistics, momentum arena, schedule position); and the 'optimizer' entry must be loadable by a stock
+    torch.optim.SGD over model.parameters()."""
+    from mrfp_amd import harness
+    from mrfp_amd.deepv3 import InjectedRandom
+    toggles = [(True, True, True), (False, True, False), (True, False, True), (True, True, False)]
+    data = [synth.synth_batch(2, 128, 128, seed=30 + i) for i in range(4)]
+    noise = [synth.synth_noise(2, seed=40 + i) for i in range(4)]
+
+    def run(tr, model, i):
+        model.rng = InjectedRandom(toggles[i], noise[i])
+        return float(tr.step(data[i][0].to(DEV), data[i][1].to(DEV)))
+
+    model, _ = _model()
+    model.train()
+    tr = harness.Trainer(model, lr=1e-2, max_iter=10)          # a short schedule: the LR factor moves visibly per step
+    for i in range(3):
+        run(tr, model, i)
+    path = str(tmp_path / "ck3.pth")
+    harness.save_checkpoint(path, model, epoch=0, optimizer=tr)
+    loss4 = run(tr, model, 3)
+    want = {k: v.clone() for k, v in model.state_dict().items()}
+    want_m = tr.opt.flat_m.clone()
+
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"epoch", "state_dict", "optimizer"}
+    osd = ck["optimizer"]
+    assert len(osd["state"]) == 192 and osd["mrfp_iteration"] == 3
+    assert abs(osd["param_groups"][0]["lr"] - 1e-2 * harness.poly_lr_factor(3, 10)) < 1e-15
+
+    model2, _ = _model()
+    model2.train()
+    tr2 = harness.Trainer(model2, lr=123.0, max_iter=10)       # wrong on purpose: everything must come from the checkpoint
+    epoch, _ = harness.load_checkpoint(path, model2, optimizer=tr2)
+    assert epoch == 0 and tr2.opt.it == 3 and tr2.opt.base_lr == 1e-2
+    loss4b = run(tr2, model2, 3)
+    assert loss4b == loss4
+    got = model2.state_dict()
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k
+    assert torch.equal(tr2.opt.flat_m, want_m)
+
+    stock = torch.optim.SGD(model2.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    stock.load_state_dict({k: v for k, v in osd.items() if k != "mrfp_iteration"})
+    bufs = [st["momentum_buffer"] for st in stock.state_dict()["state"].values()]
+    assert len(bufs) == 192

@@ -142,3 +142,78 @@ def test_wider_resnet38_trunk_matches_reference():
     with torch.no_grad():
         oe = orc.wider_resnet_a2({k: v.clone() for k, v in sd.items()}, x, False)
     np.testing.assert_allclose(stats(oe), GW["eval_out_stats"], rtol=1e-5)
+
+
+def test_well_conditioned_fixture_matches_reference():
+    """oracle vs tests/golden/mrfp_wc.npz (reference MRFPPlus at 4x192x192 with residual_gain 0.3 weights; the fixture
+    where the reference's own fp32 noise is < 1e-4, so the north_star's 1e-3 is asserted plainly on the GPU)."""
+    from golden_common import CROP as C, GWC, TAGS as T, stats, wc_case
+    sd, x, y, noise = wc_case()
+    keys = orc.trainable_keys(sd)
+    assert list(GWC["grad_keys"]) == keys
+    for tag in ("ttt",):
+        leaf = {k: sd[k].clone().requires_grad_(True) for k in keys}
+        work = {k: v.clone() for k, v in sd.items()}
+        work.update(leaf)
+        taps = {}
+        loss = orc.mrfp_forward(work, x, y, training=True, toggles=T[tag], noise=noise, taps=taps)
+        assert abs(loss.item() - float(GWC[f"{tag}_loss"])) / float(GWC[f"{tag}_loss"]) < 1e-6
+        assert float(GWC[f"{tag}_logits_noise"]) < 4e-4
+        np.testing.assert_allclose(taps["logits"].detach()[C].numpy(), GWC[f"{tag}_logits_crop"], rtol=0, atol=2e-5)
+        for name, t in taps.items():
+            if name != "logits":
+                np.testing.assert_allclose(stats(t), GWC[f"{tag}_tap/{name}"], rtol=1e-5, err_msg=name)
+        grads = torch.autograd.grad(loss, [leaf[k] for k in keys])
+        l2 = np.array([g.double().pow(2).sum().sqrt().item() for g in grads])
+        np.testing.assert_allclose(l2, GWC[f"{tag}_grad_l2"], rtol=2e-3, atol=1e-9)
+
+
+def test_resnet101_trunk_matches_reference():
+    """oracle.resnet_trunk against the numbers the reference's resnet101 (ResNet3X3, Resnet.py:338-512, 678-693) produced
+    (tests/golden/make_golden_r101.py part 1): train forward + backward, running statistics, eval."""
+    from golden_common import GR, r101_trunk_case, stats
+    sd, x, gy = r101_trunk_case()
+    assert sum(1 for k in sd if k.startswith("layer3.") and k.endswith("conv1.weight")) == 23
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    work = {k: v.clone() for k, v in sd.items()}
+    work.update(leaf)
+    ns, taps = {}, {}
+    out = orc.resnet_trunk(work, x, True, new_stats=ns, taps=taps)
+    np.testing.assert_allclose(stats(out), GR["trunk_out_stats"], rtol=1e-5)
+    np.testing.assert_allclose(out.detach()[:, 200:208].numpy(), GR["trunk_out_crop"], rtol=1e-4, atol=1e-6)
+    for name, t in taps.items():
+        np.testing.assert_allclose(stats(t), GR["trunk_tap/" + name], rtol=1e-5, err_msg=name)
+    (out * gy).sum().backward()
+    l2 = np.array([leaf[k].grad.double().pow(2).sum().sqrt().item() for k in GR["trunk_grad_keys"]])
+    np.testing.assert_allclose(l2, GR["trunk_grad_l2"], rtol=1e-3, atol=1e-9)
+    for f in GR.files:
+        if f.startswith("trunk_running/"):
+            np.testing.assert_allclose(ns[f[len("trunk_running/"):]][:8].numpy(), GR[f], rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        oe = orc.resnet_trunk({k: v.clone() for k, v in sd.items()}, x, False)
+    np.testing.assert_allclose(stats(oe), GR["trunk_eval_stats"], rtol=1e-5)
+
+
+def test_resnet101_mrfp_composition_matches_reference_forward():
+    """oracle.mrfp_forward on the trunk='resnet-101' keys against the reference's own MRFPPlus.forward run on reference
+    parts (tests/golden/make_golden_r101.py part 2) -- the network bench.py times."""
+    from golden_common import CROP as C, GR, TAGS as T, r101_comp_case, stats
+    sd, x, y, noise = r101_comp_case()
+    keys = orc.trainable_keys(sd)
+    assert list(GR["comp_grad_keys"]) == keys
+    tag = "ttt"
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    work = {k: v.clone() for k, v in sd.items()}
+    work.update(leaf)
+    taps = {}
+    loss = orc.mrfp_forward(work, x, y, training=True, toggles=T[tag], noise=noise, taps=taps)
+    assert abs(loss.item() - float(GR[f"comp_{tag}_loss"])) / float(GR[f"comp_{tag}_loss"]) < 1e-6
+    np.testing.assert_allclose(taps["logits"].detach()[C].numpy(), GR[f"comp_{tag}_logits_crop"], rtol=0, atol=5e-5)
+    for name, t in taps.items():
+        if name != "logits":
+            np.testing.assert_allclose(stats(t), GR[f"comp_{tag}_tap/{name}"], rtol=2e-5, err_msg=name)
+    grads = torch.autograd.grad(loss, [leaf[k] for k in keys])
+    l2 = np.array([g.double().pow(2).sum().sqrt().item() for g in grads])
+    np.testing.assert_allclose(l2, GR[f"comp_{tag}_grad_l2"], rtol=5e-3, atol=1e-9)
+    hist = orc.eval_hist({k: v.clone() for k, v in sd.items()}, x, y)
+    assert np.abs(hist - GR["comp_eval_hist"]).sum() <= 8
