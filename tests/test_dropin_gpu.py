@@ -77,7 +77,7 @@ target = y.numpy().astype('int64')                                              
 hist = metrics.fast_hist(pred.flatten(), target.flatten(), 19)                                       # main.py:909
 miou = metrics.evaluate_eval(hist, dataset_name='synthetic')["mean_iu"]                              # main.py:913 (prints)
 keys = list(torch.load(ck, weights_only=False)["state_dict"].keys())
-print("RESULT " + json.dumps({"losses": losses, "shown": shown, "ref": G["train3lo_losses"].tolist(),
+print("RESULT " + json.dumps({"losses": losses, "shown": shown, "ref": G["train3lo_losses"].tolist(), "ref64": G["train3lo_losses64"].tolist(),
                                "hist_diff": int(np.abs(hist - G["eval_hist"]).sum()), "hist_sum": int(hist.sum()),
                                "miou": float(miou), "miou_ref": float(G["eval_miou"]), "n_keys": len(keys),
                                "prefixed": all(k.startswith("module.") for k in keys),
@@ -91,8 +91,12 @@ def test_main_py_call_sequence_through_dropin(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     out = json.loads(line[len("RESULT "):])
-    for got, ref in zip(out["losses"], out["ref"]):                 # the reference's own SGD trajectory (lr 1e-4 pin)
-        assert abs(got - ref) / ref < 1e-3, (out["losses"], out["ref"])
+    # the reference's own SGD trajectory (lr 1e-4 pin): as close to the fp64 evaluation of the reference loop as the
+    # reference's fp32 run is (x3 + 1e-3), the criterion of tests/test_harness_gpu.py::_check_trajectory -- with the
+    # plain synthetic weights of mrfp_c1.npz the reference's third fp32 loss is itself 2.6e-3 off the fp64 one
+    for got, r32, r64 in zip(out["losses"], out["ref"], out["ref64"]):
+        assert abs(got - r64) <= 3 * abs(r32 - r64) + 1e-3 * abs(r64), (out["losses"], out["ref"], out["ref64"])
+    assert abs(out["losses"][0] - out["ref"][0]) / out["ref"][0] < 1e-4
     assert all(len(s.split(".")[1]) == 4 for s in out["shown"])
     assert out["shape"] == [2, 19, 256, 256] and out["dtype"] == "torch.float32"
     assert out["hist_diff"] <= 0.002 * out["hist_sum"]
