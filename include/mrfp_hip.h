@@ -225,6 +225,20 @@ int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64
 int64_t mrfp_conv_stats_rows(int64_t nblk);
 int64_t mrfp_conv_stats_final_first(int64_t nblk);
 int64_t mrfp_conv_stats_final_count(int64_t nblk);
+/* dgrad that feeds a BatchNorm backward (reference: autograd of Norm2d -> ReLU -> nn.Conv2d chains, Resnet.py:202-216):
+ * dx[B,Ho,Wo,0:N] = dgrad(dy[B,H,W,C], wd pack) (+ addend) as mrfp_conv_fwd with stride 1 / source stride `sstride`, and in
+ * the SAME launch the BatchNorm-backward statistics of dx, which is dL/d(BN output): per row block
+ *   bnstats[blk][0][n] = sum g',  bnstats[blk][1][n] = sum g' * (bn_x - bn_mean[n]),   g' = dx * mask,
+ *   mask = (bn_y > 0) if bn_y != NULL, else (bn_x*bn_fA[n] + bn_fS[n] > 0) if bn_fA != NULL, else 1
+ * (bn_x / bn_y: the BatchNorm's input / output, [B,Ho,Wo,N] dense, same dtype) -- the layout mrfp_stats_bwd produces, so the
+ * separate pass over (dy, x) disappears: hand rows [final_first, final_first + final_count) of bnstats (float
+ * [mrfp_conv_stats_rows(nblk)][2][N], nblk = mrfp_conv_stats_blocks(dtype, B*Ho*Wo, N, C, R, S)) to mrfp_bn_bwd_finalize
+ * with B = 1, nslab = final_count.  Needs mrfp_conv_dgrad_bnstats_ok(dtype, C, N) (C*sizeof % 128 == 0, N*sizeof % 16 == 0). */
+int mrfp_conv_dgrad_bnstats_ok(int dtype, int64_t C, int64_t N);
+int mrfp_conv_dgrad_bnstats(const void* dy, const void* wpack, void* dx, int dtype, int64_t B, int64_t H, int64_t W,
+                            int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho, int64_t Wo, int64_t pad_h, int64_t pad_w,
+                            int64_t dil, int64_t sstride, const void* addend, const void* bn_x, const void* bn_y,
+                            const float* bn_mean, const float* bn_fA, const float* bn_fS, float* bnstats, void* stream);
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q);
 int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype,
                     int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,

@@ -123,6 +123,16 @@ def _out_size(H, R, stride, pad, dil):
     return (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
 
 
+# BatchNorm-backward statistics in the dgrad epilogue of the convolution that consumes the BatchNorm's output
+# (mrfp_conv_dgrad_bnstats).  Built, tested (tests/test_ops_gpu.py) and MEASURED in round 2: it removes the statistics
+# pass (4.5 ms per bench step) but the dgrad launches get slower by the same 3.5 ms -- their epilogue now waits on
+# 16-byte global loads of x (and of y for residual blocks: 2 x 75 MB behind a 1024-channel dgrad), and a convolution's
+# epilogue moves bytes at 1.5-2.5 TB/s where the dedicated pass runs at 5.4 TB/s (profiles/r02_experiments.md).  OFF by
+# default; MRFP_FUSE_BN_BWD=1 enables it.
+FUSE_BN_BWD = [_os.environ.get("MRFP_FUSE_BN_BWD", "0") == "1"]
+FUSED_BN_BWD_HITS = [0, 0]       # [launches that produced statistics, BatchNorm backwards that consumed them]
+
+
 # ---- second stream for the weight gradients ---------------------------------------------------------------------
 USE_WGRAD_STREAM = [_os.environ.get("MRFP_WGRAD_STREAM", "1") != "0"]
 _WGRAD_STREAMS = {}
@@ -185,6 +195,9 @@ class _Conv2d(torch.autograd.Function):
             _LAST_STATS[0] = None
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, pad_h, pad_w, dil, Nphys, Ho, Wo)
+        # x is the output of a BatchNorm (+ReLU) (ops._BatchNormAct tags it): this conv's dgrad launch can produce that
+        # BatchNorm's backward statistics in its epilogue (mrfp_conv_dgrad_bnstats)
+        ctx.bn = getattr(x, "_mrfp_bnctx", None) if FUSE_BN_BWD[0] else None
         ctx.set_materialize_grads(False)
         if want_skip:
             return y, x.view_as(x)
@@ -209,8 +222,24 @@ class _Conv2d(torch.autograd.Function):
                 dskip = _chk(dskip, "dskip")
                 if dskip.dtype != x.dtype:
                     dskip = dskip.to(x.dtype)
-            call("mrfp_conv_fwd", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
-                 1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), None, stream())
+            bn = ctx.bn
+            L = _lib.lib()
+            if bn is not None and bn["x"].shape == dx.shape and bn["x"].dtype == dx.dtype and \
+                    L.mrfp_conv_dgrad_bnstats_ok(dt(dy), Nphys, Cphys):
+                # dx is dL/d(BatchNorm output): its backward statistics come out of this launch's epilogue
+                nblk = int(L.mrfp_conv_stats_blocks(dt(dy), B * H * W, Cphys, Nphys, R, S))
+                st = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Cphys, dtype=torch.float32, device=x.device)
+                call("mrfp_conv_dgrad_bnstats", ptr(dy), ptr(pk.wd), ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, R, S, H, W,
+                     dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), ptr(bn["x"]),
+                     ptr(x if bn["mask_from_y"] else None), ptr(bn["mean"]), ptr(bn["fA"]), ptr(bn["fS"]), ptr(st), stream())
+                first, cnt = int(L.mrfp_conv_stats_final_first(nblk)), int(L.mrfp_conv_stats_final_count(nblk))
+                # (the version check in ops._BatchNormAct.backward rejects the statistics if autograd accumulated another
+                #  gradient into this tensor in place before handing it on)
+                dx._mrfp_bnstats = (st[first * 2 * Cphys:(first + cnt) * 2 * Cphys], cnt, bn["token"], dx._version)
+                FUSED_BN_BWD_HITS[0] += 1
+            else:
+                call("mrfp_conv_fwd", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
+                     1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), None, stream())
         if ctx.needs_input_grad[1]:
             M, Q = B * Ho * Wo, R * S * Cphys
             sink = grad_sink(weight)      # the parameter's slot in the flat gradient arena, when the harness owns it

@@ -38,6 +38,15 @@ struct ConvP {
     const float* bias;  // [N] or null
     const char* addend; // [M][ldy] (T) added to the result in the epilogue, or null (fused gradient accumulation)
     float* colstats;    // [row blocks][2][ldy] per-channel sum / sum of squares of the stored output, or null
+    // BNB kernels (dgrad feeding a BatchNorm backward): the stored output is dL/d(BN output); its BatchNorm-backward
+    // statistics  sum g'  and  sum g' * (x - mean)  with  g' = g * [ReLU mask]  are produced here, per row block, instead
+    // of by a separate pass over (g, x):  bnx = BN input [M][ldy], bny = BN output for the mask (residual blocks) or null,
+    // bnA / bnS = forward apply coefficients for the recomputed mask (x*A+S > 0) or null (no ReLU), bnmean [ldy].
+    const char* bnx;
+    const char* bny;
+    const float* bnmean;
+    const float* bnA;
+    const float* bnS;
     int B, H, W, C;
     int N, ldy;
     int R, S, Ho, Wo;
@@ -123,6 +132,33 @@ __device__ __forceinline__ uint4 bload(const __amdgpu_buffer_rsrc_t& r, unsigned
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Asynchronous LDS-DMA for the multi-buffer pipelines.  The compiler's waitcnt pass treats a `buffer_load ... lds` issued
+// through the builtin as an LDS store that ANY later ds_read may alias and puts `s_waitcnt vmcnt(0)` in front of the first
+// fragment read after it -- which silently serialises "tile k+1 streams in while tile k is multiplied" (the round-1
+// double-buffered variants all measured slower for exactly this reason: the ISA of their K loop reads issue, vmcnt(0),
+// ds_read).  Issued from inline assembly the transfer is invisible to that pass; ordering is then ours: a counted
+// `s_waitcnt vmcnt(N)` (dma_wait) before the workgroup barrier that publishes a stage, and vmcnt(0) before LDS is reused
+// by the epilogue.  LDS destination of lane l = m0 + 16*l (m0 = wave-uniform LDS byte address of the 1 KiB piece).
+typedef int __attribute__((ext_vector_type(4))) i32x4;
+__device__ __forceinline__ i32x4 rsrc_words(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);      // stride 0
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16_async(const i32x4& rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc));   // (m0 is a reserved register: it cannot be listed as a clobber; nothing
+                                                             //  else in these kernels uses it -- checked in the ISA)
+}
+template <int N> __device__ __forceinline__ void dma_wait() {      // all but the N youngest vector-memory operations done
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
 // ALIGNED: the channel count fills whole K tiles (C*sizeof(T) % 128 == 0), so a K tile never straddles a
 //          filter tap and the tap (r,s) is tracked in scalar registers; otherwise every thread tracks the tap
 //          of its own 16-byte chunk.
@@ -185,7 +221,7 @@ template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a,
     return r;
 }
 
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
@@ -205,6 +241,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
     const int pixbytes = p.C * (int)sizeof(T);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
+    constexpr bool ASYNC = DMA && NBUF >= 2;         // multi-stage LDS ring filled by asynchronous LDS-DMA (dma16_async)
+    const i32x4 xw = rsrc_words(p.x, p.xbytes), ww = rsrc_words(p.w, p.wbytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the ring
 
     // fixed per-thread gather state for its SA rows of the A tile
     int a_ih0[SA], a_iw0[SA];
@@ -261,7 +300,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
                 const bool ok = qok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 voff = ok ? a_base[i] + tap : kOOB;
             }
-            if (DMA)
+            if (ASYNC)
+                dma16_async(xw, lds0 + (unsigned)(dbuf * BUF + (wrow + i * RSTEP) * 128), voff);
+            else if (DMA)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sA0 + dbuf * BUF + (wrow + i * RSTEP) * 128), 16,
                                                          (int)voff, 0, 0, 0);
             else
@@ -274,7 +315,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const unsigned voff = (b_base[i] >= kOOB || !qok) ? kOOB : b_base[i] + qoff;
-            if (DMA)
+            if (ASYNC)
+                dma16_async(ww, lds0 + (unsigned)(BM * 128 + dbuf * BUF + (wrow + i * RSTEP) * 128), voff);
+            else if (DMA)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sB0 + dbuf * BUF + (wrow + i * RSTEP) * 128), 16,
                                                          (int)voff, 0, 0, 0);
             else
@@ -359,7 +402,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
                 for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
     };
-    if (DMA && NBUF == 1) {
+    if constexpr (DMA && NBUF == 1) {
         // single LDS buffer filled by LDS-DMA: no register staging and no ds_write at all; the fill latency of a
         // workgroup is exposed and hidden only by the other workgroups of the CU (more of them fit: fewer registers)
         for (int kt = 0; kt < nkt; ++kt) {
@@ -368,16 +411,25 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
             compute(0);
             __syncthreads();          // everybody is done reading before the next fill
         }
-    } else if (DMA) {
-        // tile k+1 streams into the other LDS buffer while tile k is multiplied; __syncthreads() = vmcnt(0) (this
-        // wave's DMA pieces have landed) + barrier (so have everybody else's, and everybody is done reading tile k)
-        load_tile(0, ra, rb, 0);
-        __syncthreads();
+    } else if constexpr (DMA) {
+        // NBUF-stage LDS ring, NBUF-1 K tiles in flight per workgroup.  Iteration kt: wait until this wave's pieces of
+        // tile kt have landed (all but the (NBUF-2)*NP youngest transfers), barrier (everybody's have, and everybody has
+        // finished multiplying tile kt-1, whose slot is the one refilled next), issue tile kt+NBUF-1, multiply tile kt.
+        // ONE barrier per K tile and no wave ever waits for a transfer it has just issued.
+        constexpr int NP = SA + SB;                  // DMA pieces per wave per tile
+        static_assert((NBUF - 2) * NP < 64, "vmcnt range");
+#pragma unroll
+        for (int s = 0; s < NBUF - 1; ++s)
+            if (s < nkt) load_tile(s, ra, rb, s);
         for (int kt = 0; kt < nkt; ++kt) {
-            if (kt + 1 < nkt) load_tile(kt + 1, ra, rb, (kt + 1) & 1);
-            compute(kt & 1);
-            __syncthreads();
+            if (kt + NBUF - 1 <= nkt) dma_wait<(NBUF - 2) * NP>();      // NBUF-2 younger tiles may still be in flight
+            else dma_wait<0>();                                        // tail: fewer tiles behind this one
+            __builtin_amdgcn_s_barrier();
+            if (kt + NBUF - 1 < nkt) load_tile(kt + NBUF - 1, ra, rb, (kt + NBUF - 1) % NBUF);
+            compute(kt % NBUF);
         }
+        dma_wait<0>();
+        __builtin_amdgcn_s_barrier();             // everybody is done reading the ring: the epilogue reuses it
     } else {
         load_tile(0, ra, rb, 0);
         store_tile(0, ra, rb);
@@ -422,6 +474,21 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
         bv[j] = (p.bias && n < p.N && (M16 || j < TN)) ? p.bias[n] : 0.f;
         cs[j] = 0.f;
         cq[j] = 0.f;
+    }
+    // BNB: a lane's read-out chunk column is the same for every row it handles, so its EPC channels' coefficients live in
+    // registers and the two sums are per-lane accumulators, folded over the rows at the end
+    float b_mu[BNB ? EPC : 1], b_fa[BNB ? EPC : 1], b_fs[BNB ? EPC : 1], b_s0[BNB ? EPC : 1], b_s1[BNB ? EPC : 1];
+    if constexpr (BNB) {
+        const int n = (WIDE ? n0 : nb) + (lane % CPRW) * EPC;
+#pragma unroll
+        for (int u = 0; u < EPC; ++u) {
+            const bool in = n + u < p.N;
+            b_mu[u] = in ? p.bnmean[n + u] : 0.f;
+            b_fa[u] = (in && p.bnA) ? p.bnA[n + u] : 0.f;
+            b_fs[u] = (in && p.bnS) ? p.bnS[n + u] : 0.f;
+            b_s0[u] = 0.f;
+            b_s1[u] = 0.f;
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -483,6 +550,19 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
                     }
                     v = chunk_add<T>(v, av);
                 }
+                if constexpr (BNB) {      // (host guarantees N % EPC == 0 for these launches: every chunk is full)
+                    const uint4 xv = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.bnx) + (size_t)m * p.ldy + n);
+                    uint4 yv = make_uint4(0u, 0u, 0u, 0u);
+                    if (p.bny) yv = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.bny) + (size_t)m * p.ldy + n);
+#pragma unroll
+                    for (int u = 0; u < EPC; ++u) {
+                        const float xf = to_f(chunk_get<T>(xv, u));
+                        const float gate = p.bny ? to_f(chunk_get<T>(yv, u)) : (p.bnA ? xf * b_fa[u] + b_fs[u] : 1.f);
+                        const float g = gate > 0.f ? to_f(chunk_get<T>(v, u)) : 0.f;
+                        b_s0[u] += g;
+                        b_s1[u] += g * (xf - b_mu[u]);
+                    }
+                }
                 if (full) {
                     *reinterpret_cast<uint4*>(dst) = v;
                 } else {
@@ -495,7 +575,47 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
         if constexpr (WIDE) __syncthreads();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if (p.colstats) {
+    if constexpr (BNB) {
+        // fold the RPI row-lanes of every chunk column (lanes ch, ch + CPRW, ch + 2 CPRW, ...) in a fixed order
+#pragma unroll
+        for (int off = CPRW; off < 64; off <<= 1)
+#pragma unroll
+            for (int u = 0; u < EPC; ++u) {
+                b_s0[u] += __shfl_xor(b_s0[u], off, 64);
+                b_s1[u] += __shfl_xor(b_s1[u], off, 64);
+            }
+        float* out = p.colstats + (size_t)((tile / ntn) * WM + wm) * 2 * p.ldy;
+        const int ch = lane % CPRW;
+        if constexpr (WIDE) {
+            // the WN waves of a wave row read out different rows of the same columns: combine them through LDS
+            // (fixed order: bitwise reproducible), behind the staging area
+            float* red = reinterpret_cast<float*>(smem + WM * 32 * EPITCH) + wm * (WN * 2 * BN);
+            if (lane < CPRW) {
+#pragma unroll
+                for (int u = 0; u < EPC; ++u) {
+                    red[(wn * 2 + 0) * BN + ch * EPC + u] = b_s0[u];
+                    red[(wn * 2 + 1) * BN + ch * EPC + u] = b_s1[u];
+                }
+            }
+            __syncthreads();
+            for (int o = wn * 64 + lane; o < 2 * BN; o += WN * 64) {
+                const int st = o / BN, c = o - st * BN;
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) a += red[(w * 2 + st) * BN + c];
+                if (n0 + c < p.N) out[st * p.ldy + n0 + c] = a;
+            }
+        } else if (lane < CPRW) {
+#pragma unroll
+            for (int u = 0; u < EPC; ++u) {
+                const int n = nb + ch * EPC + u;
+                if (n < p.N) {
+                    out[n] = b_s0[u];
+                    out[p.ldy + n] = b_s1[u];
+                }
+            }
+        }
+    } else if (p.colstats) {
         // a lane holds 16 of the 32 rows of each block column, its partner (lane ^ 32) the other 16
         float* out = p.colstats + (size_t)((tile / ntn) * WM + wm) * 2 * p.ldy;
         if constexpr (M16) {
@@ -555,19 +675,20 @@ __global__ __launch_bounds__(256) void compact_stats_kernel(float* __restrict__ 
     if (ty == 0 && c < C2) st[(size_t)(nblk + g) * C2 + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
 }
 
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA>
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false>
 static int launch_igemm_nb(const ConvP& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int EP = WM * WN * 32 * (32 * TN * (int)sizeof(T) + 16);     // epilogue staging
+    // epilogue staging (+16 bytes of pitch per row, also in the wide layout) + the cross-wave fold of the BNB sums
+    constexpr int EP = WM * WN * 32 * (32 * TN * (int)sizeof(T) + 16) + (BNB ? WM * WN * 2 * BN * 4 : 0);
     const int lds = NBUF * (BM + BN) * 128 > EP ? NBUF * (BM + BN) * 128 : EP;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF, TM, TN, DMA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF, TM, TN, DMA, BNB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF, TM, TN, DMA>), dim3((unsigned)tiles),
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, ALIGNED, STRIDED, NBUF, TM, TN, DMA, BNB>), dim3((unsigned)tiles),
                        dim3(64 * WM * WN), lds, st, p);
     MRFP_LAUNCH_CHECK();
     return 0;
@@ -575,20 +696,30 @@ static int launch_igemm_nb(const ConvP& p, hipStream_t st) {
 
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int TM, int TN>
 static int launch_igemm(const ConvP& p, hipStream_t st) {
-    // MRFP_CONV_DMA (A/B measurements): 0 = register staging everywhere; 1 = LDS-DMA (two buffers) for the 8-wave tile
-    // only; 2 = LDS-DMA with two buffers everywhere; 3 (default) = LDS-DMA everywhere, ONE buffer for the 4-wave tiles
-    // (no staging registers, no ds_write: 112 / 90 registers -> 4-5 workgroups per CU hide each other's fill latency;
-    // measured against mode 1: M = 36 864 3x3 layers 630 -> 792 TF/s, 128x128 tile 844 -> 919, fwd+dgrad 31.8 -> 30.0 ms
-    // per step) and two for the 8-wave tile (one buffer there: 902 -> 862); 4 = one buffer everywhere.
-    static int dma = -1;
+    // Staging of the K tiles (MRFP_CONV_DMA, A/B measurements): 0 = register staging, one LDS buffer; 3 (default) = LDS-DMA
+    // everywhere: the 4-wave tiles fill ONE buffer with the builtin (fill, barrier, multiply, barrier; the 3-5 co-resident
+    // workgroups of a CU hide each other's fill latency), the 8-wave tile runs the asynchronous ring.
+    // MRFP_CONV_NBUF=2: every tile runs a 2-stage ring filled by asynchronous LDS-DMA (conv_igemm_kernel).  Measured in
+    // round 2 (tools/ab_nbuf.sh, profiles/r02_experiments.md): -5 % on every shape (3 stages: -25 %) -- a second stage
+    // costs a co-resident workgroup, and the fill path (L2 -> LDS, ~14 TB/s) is throughput-bound, not latency-bound.
+    static int dma = -1, nbuf = -1;
     if (dma < 0) {
         const char* e = getenv("MRFP_CONV_DMA");
         dma = e ? atoi(e) : 3;
+        e = getenv("MRFP_CONV_NBUF");
+        nbuf = e ? atoi(e) : 0;
     }
-    if ((dma == 1 && TM * TN >= 8) || dma == 2) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
-    if ((dma == 3 && TM * TN < 8) || dma == 4) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, true>(p, st);
-    if (dma == 3) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
-    return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, false>(p, st);       // register staging, one LDS buffer
+    if constexpr (ALIGNED) {      // dgrad + BatchNorm-backward statistics (mrfp_conv_dgrad_bnstats): aligned channel counts only
+        if (p.bnx) {
+            if constexpr (sizeof(T) == 2 && TM * TN >= 8) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true, true>(p, st);
+            else return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, true, true>(p, st);
+        }
+    }
+    if (dma == 0) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, false>(p, st);   // register staging
+    if constexpr (sizeof(T) == 2) {
+        if (nbuf >= 2 || TM * TN >= 8) return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 2, TM, TN, true>(p, st);
+    }
+    return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, true>(p, st);
 }
 
 template <typename T, int WM, int WN, int TM, int TN>
@@ -785,10 +916,11 @@ using namespace mrfp;
 
 extern "C" {
 
-int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
-                  int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
-                  int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
-                  float* colstats, void* stream) {
+static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
+                         int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
+                         int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
+                         float* colstats, const void* bnx, const void* bny, const float* bnmean, const float* bnA,
+                         const float* bnS, void* stream) {
     MRFP_CHECK(!addend || aligned16(addend), "conv_fwd: addend must be 16-byte aligned");
     MRFP_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
                "conv_fwd: bad arguments");
@@ -800,10 +932,16 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
     MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
     ConvP p;
     p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias; p.addend = (const char*)addend; p.colstats = colstats;
+    p.bnx = (const char*)bnx; p.bny = (const char*)bny; p.bnmean = bnmean; p.bnA = bnA; p.bnS = bnS;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
     p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    if (bnx) {
+        MRFP_CHECK(colstats && bnmean && aligned16(bnx) && (!bny || aligned16(bny)), "conv_dgrad_bnstats: bad arguments");
+        MRFP_CHECK((p.cpr & 7) == 0 && (N * esz) % 16 == 0 && ldy == N,
+                   "conv_dgrad_bnstats: needs C*esz %% 128 == 0 and a dense output of whole chunks (query mrfp_conv_dgrad_bnstats_ok)");
+    }
     const int64_t xb = B * H * W * C * esz, wb = N * (int64_t)p.kchunks * 16;
     MRFP_CHECK(xb < (int64_t)kOOB && wb < (int64_t)kOOB, "conv_fwd: tensor exceeds the 3.75 GB buffer-descriptor range");
     p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
@@ -824,6 +962,28 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
         MRFP_LAUNCH_CHECK();
     }
     return 0;
+}
+
+int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
+                  int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
+                  int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
+                  float* colstats, void* stream) {
+    return conv_fwd_impl(x, wpack, bias, y, dtype, B, H, W, C, N, ldy, R, S, Ho, Wo, stride, pad_h, pad_w, dil, sstride, addend,
+                         colstats, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int mrfp_conv_dgrad_bnstats_ok(int dtype, int64_t C, int64_t N) {
+    const int esz = dtype == MRFP_F32 ? 4 : 2;
+    return (C * esz) % 128 == 0 && (N * esz) % 16 == 0;
+}
+
+int mrfp_conv_dgrad_bnstats(const void* dy, const void* wpack, void* dx, int dtype, int64_t B, int64_t H, int64_t W,
+                            int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho, int64_t Wo, int64_t pad_h, int64_t pad_w,
+                            int64_t dil, int64_t sstride, const void* addend, const void* bn_x, const void* bn_y,
+                            const float* bn_mean, const float* bn_fA, const float* bn_fS, float* bnstats, void* stream) {
+    MRFP_CHECK(bn_x && bn_mean && bnstats, "conv_dgrad_bnstats: bn_x / bn_mean / bnstats are required");
+    return conv_fwd_impl(dy, wpack, nullptr, dx, dtype, B, H, W, C, N, N, R, S, Ho, Wo, 1, pad_h, pad_w, dil, sstride, addend,
+                         bnstats, bn_x, bn_y, bn_mean, bn_fA, bn_fS, stream);
 }
 
 int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S) {

@@ -211,6 +211,16 @@ class _BatchNormAct(torch.autograd.Function):
         ctx.remask = relu and res is None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, y if keep_y else None, w32, mean, invstd, A, S)
+        if plan is None and (x.requires_grad or (weight is not None and weight.requires_grad)):
+            # the convolution that consumes y can produce this layer's backward statistics in its dgrad epilogue
+            # (mrfp_amd/conv.py, mrfp_conv_dgrad_bnstats); the token ties those statistics to THIS layer
+            ctx.token = object()
+            # (no reference to y itself in here: y -> dict -> y would be a cycle that keeps the activation alive until the
+            #  garbage collector runs; the consuming convolution has y anyway -- it is its input)
+            y._mrfp_bnctx = {"x": x, "mask_from_y": keep_y, "mean": mean, "fA": A if ctx.remask else None,
+                             "fS": S if ctx.remask else None, "token": ctx.token}
+        else:
+            ctx.token = None
         return y
 
     @staticmethod
@@ -220,12 +230,22 @@ class _BatchNormAct(torch.autograd.Function):
         plan = ctx.plan
         B, Ho, Wo, C, *_ = _geom(x, plan)
         fA, fS = (A, S) if ctx.remask else (None, None)
-        nslab, ws = _stats_bwd(dy, x, y, mean, False, plan, fA, fS)
+        fused = getattr(dy, "_mrfp_bnstats", None)
+        if fused is not None and ctx.token is not None and fused[2] is ctx.token and fused[3] == dy._version and \
+                fused[0].numel() == fused[1] * 2 * C:
+            # dy came straight out of the dgrad launch of the one convolution that consumes this layer's output, and that
+            # launch already summed dy' and dy'*(x - mean) per row block: no pass over (dy, x) here
+            ws, nb_, nslab = fused[0], 1, fused[1]
+            from . import conv as _conv
+            _conv.FUSED_BN_BWD_HITS[1] += 1
+        else:
+            nslab, ws = _stats_bwd(dy, x, y, mean, False, plan, fA, fS)
+            nb_ = B
         out = torch.empty(5 * C, dtype=torch.float32, device=dy.device)
         dw, db, P, Q, R = (out[i * C:(i + 1) * C] for i in range(5))
         sw = grad_sink(ctx.wparam) if ctx.needs_input_grad[1] else None
         sb = grad_sink(ctx.bparam) if ctx.needs_input_grad[2] else None
-        call("mrfp_bn_bwd_finalize", ptr(ws), B, nslab, B * Ho * Wo, C, ptr(w32), ptr(mean), ptr(invstd),
+        call("mrfp_bn_bwd_finalize", ptr(ws), nb_, nslab, B * Ho * Wo, C, ptr(w32), ptr(mean), ptr(invstd),
              ptr(sw if sw is not None else dw), ptr(sb if sb is not None else db), ptr(P), ptr(Q), ptr(R), stream())
         if not ctx.training:
             # module in eval mode (running statistics are constants): the same dweight / dbias sums, but the input

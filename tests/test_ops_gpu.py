@@ -331,3 +331,72 @@ def test_concat_channels(dtype, chans):
     for x, c in zip(xd, chans):
         assert torch.equal(x.grad, gy[:, c0:c0 + c])
         c0 += c
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("case", [
+    # (B, Cin, H, W, Cmid, k, stride, dil, residual)   conv_a -> BN(+res) -> ReLU -> conv_b(k, stride, dil)
+    (2, 64, 20, 18, 64, 3, 1, 1, False),        # bn -> relu -> 3x3: mask recomputed from x*A+S
+    (3, 128, 12, 12, 256, 1, 1, 1, True),       # bn + residual -> relu -> 1x1: mask from the stored output
+    (2, 64, 16, 16, 128, 3, 2, 1, False),       # strided consumer: the dgrad launch runs with a source stride
+    (2, 64, 9, 11, 64, 3, 1, 2, False),         # dilated consumer, ragged M (not a multiple of any tile)
+    (2, 64, 48, 48, 64, 1, 1, 1, True),         # N = 64 -> the 256x64 tile (no wide epilogue)
+    (16, 64, 24, 24, 256, 3, 1, 1, False),      # M = 9216 rows: several row blocks per launch
+])
+def test_bn_backward_statistics_from_the_dgrad_epilogue(dtype, tol, case):
+    """mrfp_conv_dgrad_bnstats: the convolution that consumes a BatchNorm(+ReLU) output produces that layer's backward
+    statistics (sum dy', sum dy'(x - mean)) in its dgrad epilogue.  Checked against (a) the same chain with the separate
+    statistics pass (MRFP_FUSE_BN_BWD off) and (b) torch autograd on the CPU in fp32."""
+    import torch.nn.functional as F
+    from mrfp_amd import conv, ops
+    B, Cin, H, W, Cm, k, st, dil, with_res = case
+    g = torch.Generator().manual_seed(sum(case[:8]))
+    x0 = torch.randn(B, Cin, H, W, generator=g)
+    wa = torch.randn(Cm, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5
+    wb = torch.randn(64, Cm, k, k, generator=g) * (1.0 / (Cm * k * k)) ** 0.5     # 64 channels: whole 128-byte K tiles in the dgrad
+    gam, bet = torch.rand(Cm, generator=g) + 0.5, torch.randn(Cm, generator=g) * 0.2
+    res = torch.randn(B, Cm, H, W, generator=g) if with_res else None
+    if dtype != torch.float32:
+        x0, wa, wb = x0.to(dtype).float(), wa.to(dtype).float(), wb.to(dtype).float()
+        res = res.to(dtype).float() if with_res else None
+    pad = dil * (k - 1) // 2
+
+    def cpu():
+        x, a, b2, ga, be = (t.clone().requires_grad_(True) for t in (x0, wa, wb, gam, bet))
+        h = F.batch_norm(F.conv2d(x, a), None, None, ga, be, True, 0.1, 1e-5)
+        h = F.relu(h + res) if with_res else F.relu(h)
+        y = F.conv2d(h, b2, None, st, pad, dil)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+        y.backward(gy)
+        return gy, (x.grad, a.grad, ga.grad, be.grad)
+
+    def hip(gy, fuse):
+        conv.FUSE_BN_BWD[0] = fuse
+        hits = list(conv.FUSED_BN_BWD_HITS)
+        x = x0.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        a, b2 = wa.to(DEV).requires_grad_(True), wb.to(DEV).requires_grad_(True)
+        ga, be = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
+        r = res.to(DEV, dtype).contiguous(memory_format=torch.channels_last) if with_res else None
+        h = ops.batch_norm_act(conv.conv2d(x, a, None, 1, 0, 1), ga, be, None, None, training=True, relu=True, res=r)
+        y = conv.conv2d(h, b2, None, st, pad, dil)
+        y.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+        used = (conv.FUSED_BN_BWD_HITS[0] - hits[0], conv.FUSED_BN_BWD_HITS[1] - hits[1])
+        return (x.grad.float().cpu(), a.grad.cpu(), ga.grad.cpu(), be.grad.cpu()), used
+
+    gy, ref = cpu()
+    if dtype != torch.float32:
+        gy = gy.to(dtype).float()
+    was = conv.FUSE_BN_BWD[0]
+    try:
+        plain, used0 = hip(gy, False)
+        fused, used1 = hip(gy, True)
+    finally:
+        conv.FUSE_BN_BWD[0] = was
+    assert used0 == (0, 0) and used1 == (1, 1), (used0, used1)        # the fused path really ran, and only when asked
+    for name, f, p_, r_ in zip(("dx", "dw", "dgamma", "dbeta"), fused, plain, ref):
+        scale = r_.abs().max().item()
+        assert (f - p_).abs().max().item() <= 0.05 * tol * scale + 1e-7, name       # same numbers up to summation order
+        if dtype == torch.float32:
+            assert (f - r_).abs().max().item() <= tol * scale, name
+        else:       # bf16 activations flip the ReLU mask of a few near-zero pre-activations: compare in the L2 norm
+            assert ((f - r_).norm() / r_.norm()).item() <= 2.5 * tol, name

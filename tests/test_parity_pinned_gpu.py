@@ -162,8 +162,9 @@ def test_r101_trunk_train_vs_reference_golden():
         if err > 3 * noise + 2e-4:
             outside.append((k, err, noise))
     assert len(outside) <= 0.02 * n_t, outside
-    for k, r in zip(GR["trunk_grad_keys"], GR["trunk_grad_l2"]):     # the reference run's own numbers
-        if r > 1e-6:
+    floor = 1e-4 * float(np.median(GR["trunk_grad_l2"]))             # below: mathematically-zero gradients (a bias in
+    for k, r in zip(GR["trunk_grad_keys"], GR["trunk_grad_l2"]):     # front of an InstanceNorm), rounding noise only
+        if r > floor:                                                # the reference run's own numbers
             got = params[trunk_key(str(k))].grad.double().norm().item()
             assert abs(got - r) / r < 5e-3, (k, got, r)
     msd = m.state_dict()
