@@ -220,6 +220,11 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
  * BatchNorm statistics pass over the conv output disappears (feed it to mrfp_bn_finalize with B = 1,
  * nslab = nblk, count = B*Ho*Wo). */
 int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S);
+/* The K-loop gathers through 32-bit buffer-descriptor offsets, so one launch reads at most 3.75 GB of input; a larger
+ * activation (BASELINE.json configs[4] at 16 images per GPU: 16 x 256 x 512 x 1024 bf16 = 4.3 GB) is walked in batch ranges
+ * by mrfp_conv_fwd / mrfp_conv_wgrad themselves (one image must stay below the limit).  Returns 1 when B images of
+ * image_bytes = H*W*C*sizeof(dtype) run as ONE launch -- only then are the fused per-row-block statistics available. */
+int mrfp_conv_single_launch(int64_t B, int64_t image_bytes);
 /* colstats must hold mrfp_conv_stats_rows(nblk) rows of 2*ldy floats; large launches fold their row blocks into
  * 64 groups appended behind them: hand rows [final_first, final_first + final_count) to mrfp_bn_finalize. */
 int64_t mrfp_conv_stats_rows(int64_t nblk);

@@ -181,9 +181,9 @@ class _Conv2d(torch.autograd.Function):
         pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
         y = empty_cl(B, Nphys, Ho, Wo, x.dtype, x.device)
         stats = None
-        if bias is None and FUSE_STATS[0]:
+        L = _lib.lib()
+        if bias is None and FUSE_STATS[0] and L.mrfp_conv_single_launch(B, H * W * Cphys * x.element_size()):
             # no bias = a convolution that feeds a normalisation layer: let the epilogue produce its statistics
-            L = _lib.lib()
             nblk = int(L.mrfp_conv_stats_blocks(dt(x), B * Ho * Wo, Nphys, Cphys, R, S))
             stats = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Nphys, dtype=torch.float32, device=x.device)
         call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
@@ -225,7 +225,8 @@ class _Conv2d(torch.autograd.Function):
             bn = ctx.bn
             L = _lib.lib()
             if bn is not None and bn["x"].shape == dx.shape and bn["x"].dtype == dx.dtype and \
-                    L.mrfp_conv_dgrad_bnstats_ok(dt(dy), Nphys, Cphys):
+                    L.mrfp_conv_dgrad_bnstats_ok(dt(dy), Nphys, Cphys) and \
+                    L.mrfp_conv_single_launch(B, Ho * Wo * Nphys * dy.element_size()):
                 # dx is dL/d(BatchNorm output): its backward statistics come out of this launch's epilogue
                 nblk = int(L.mrfp_conv_stats_blocks(dt(dy), B * H * W, Cphys, Nphys, R, S))
                 st = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Cphys, dtype=torch.float32, device=x.device)

@@ -740,6 +740,7 @@ static bool use_big_tile(const ConvP& p, int esz) {
         g_big = e ? atoi(e) : 0;
     }
     if (!g_big || esz != 2 || p.N <= 64) return false;
+    if (g_big == 2) return true;         // A/B measurements: the 8-wave tile wherever it is legal
     const int64_t m256 = (p.M + 255) / 256, n256 = (p.N + 255) / 256;
     const int nkt = (p.kchunks + 7) >> 3;
     return p.N >= 192 && n256 * 256 - p.N <= 64 && nkt >= 18 && m256 * n256 >= 448;
@@ -942,17 +943,39 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
         MRFP_CHECK((p.cpr & 7) == 0 && (N * esz) % 16 == 0 && ldy == N,
                    "conv_dgrad_bnstats: needs C*esz %% 128 == 0 and a dense output of whole chunks (query mrfp_conv_dgrad_bnstats_ok)");
     }
-    const int64_t xb = B * H * W * C * esz, wb = N * (int64_t)p.kchunks * 16;
-    MRFP_CHECK(xb < (int64_t)kOOB && wb < (int64_t)kOOB, "conv_fwd: tensor exceeds the 3.75 GB buffer-descriptor range");
-    p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
+    const int64_t img = H * W * C * esz, wb = N * (int64_t)p.kchunks * 16;      // bytes of one input image, of the pack
+    MRFP_CHECK(img < (int64_t)kOOB && wb < (int64_t)kOOB,
+               "conv_fwd: one input image / the weight pack exceeds the 3.75 GB buffer-descriptor range");
+    // The gather addresses of the K loop are 32-bit offsets into a buffer descriptor (hardware bounds check = zero fill
+    // for padding and tails), so ONE launch can read at most kOOB bytes of input.  A larger activation (configs[4] at 16
+    // images per GPU: 16 x 256 x 512 x 1024 bf16 = 4.3 GB) runs as several launches over batch ranges; images are
+    // independent in a convolution, so nothing else changes.  (The fused per-row-block statistics are per launch: the
+    // caller does not ask for them on such tensors, mrfp_conv_single_launch() tells it.)
+    const int64_t bmax = (int64_t)(kOOB - 1) / img;          // images per launch
+    const bool chunked = B > bmax;
+    MRFP_CHECK(!chunked || !colstats, "conv_fwd: fused statistics are not available for inputs above 3.75 GB (see mrfp_conv_single_launch)");
+    int dbg_drop = 0;
     {   // timing-only diagnostics: zero-record descriptors drop that operand's traffic, instruction stream unchanged
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
-        if (dbg & 1) p.xbytes = 0;
-        if (dbg & 2) p.wbytes = 0;
+        dbg_drop = dbg;
     }
-    const int rc = dtype == MRFP_F32 ? run_igemm<float>(p, (hipStream_t)stream)
-                   : dtype == MRFP_F16 ? run_igemm<f16>(p, (hipStream_t)stream) : run_igemm<bf16>(p, (hipStream_t)stream);
+    int rc = 0;
+    for (int64_t b0 = 0; b0 < B && !rc; b0 += bmax) {
+        const int64_t bc = B - b0 < bmax ? B - b0 : bmax;
+        const int64_t m0 = b0 * Ho * Wo;
+        p.B = (int)bc;
+        p.M = (int)(bc * Ho * Wo);
+        p.x = (const char*)x + b0 * img;
+        p.y = (char*)y + m0 * ldy * esz;
+        p.addend = addend ? (const char*)addend + m0 * ldy * esz : nullptr;
+        p.bnx = bnx ? (const char*)bnx + m0 * ldy * esz : nullptr;
+        p.bny = bny ? (const char*)bny + m0 * ldy * esz : nullptr;
+        p.xbytes = (dbg_drop & 1) ? 0u : (unsigned)(bc * img);
+        p.wbytes = (dbg_drop & 2) ? 0u : (unsigned)wb;
+        rc = dtype == MRFP_F32 ? run_igemm<float>(p, (hipStream_t)stream)
+             : dtype == MRFP_F16 ? run_igemm<f16>(p, (hipStream_t)stream) : run_igemm<bf16>(p, (hipStream_t)stream);
+    }
     if (rc || !colstats) return rc;
     const int64_t nblk = stats_row_blocks(p, esz);
     if (nblk > kCompactAbove) {
@@ -962,6 +985,11 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
         MRFP_LAUNCH_CHECK();
     }
     return 0;
+}
+
+/* 1 when a convolution over an input of B images of `image_bytes` bytes runs as ONE launch (fused statistics available) */
+int mrfp_conv_single_launch(int64_t B, int64_t image_bytes) {
+    return image_bytes > 0 && image_bytes < (int64_t)kOOB && B <= (int64_t)(kOOB - 1) / image_bytes;
 }
 
 int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
@@ -1340,7 +1368,7 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
 // Threads walk the SLAB order (4 consecutive channels each, 16-byte loads: the slabs are ~20x the size of dW, so
 // their reads are the ones that must coalesce); the OIHW stores are 4-byte scattered but few.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int N, int Q, int C, int Ctrue, int RS,
-                                    float* __restrict__ dw) {
+                                    float* __restrict__ dw, int accumulate) {
     const int64_t total4 = (int64_t)N * Q / 4, NQ = (int64_t)N * Q;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = i * 4;
@@ -1354,6 +1382,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         float* d = dw + ((size_t)n * Ctrue + c) * RS + rs;
+        if (accumulate) {            // a later batch range of an activation that is read in several launches
+            acc.x += d[0];
+            if (c + 1 < Ctrue) acc.y += d[RS];
+            if (c + 2 < Ctrue) acc.z += d[2 * RS];
+            if (c + 3 < Ctrue) acc.w += d[3 * RS];
+        }
         d[0] = acc.x;
         if (c + 1 < Ctrue) d[RS] = acc.y;
         if (c + 2 < Ctrue) d[2 * RS] = acc.z;
@@ -1387,7 +1421,7 @@ static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
     return launch_wgrad_v<T, WM, WN, false>(p, splits, st);
 }
 
-static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen) {
+static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen, int64_t cap = 0) {
     wm = N <= 64 ? 1 : 2;
     const int wn = 4 / wm;
     const int64_t tiles = ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
@@ -1418,6 +1452,7 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& s
     }
     if (sp < 1) sp = 1;
     if (sp > nkt) sp = nkt;
+    if (cap > 0 && sp > cap) sp = cap;         // (a batch range of a larger call: the workspace was sized for the whole call)
     int64_t per = (nkt + sp - 1) / sp;        // K' tiles per split
     sp = (nkt + per - 1) / per;
     splits = (int)sp;
@@ -1451,31 +1486,44 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldn = (int)ldn;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil;
-    p.M = (int)(B * Ho * Wo); p.Q = (int)(R * S * C);
-    const int64_t xb = B * H * W * C * esz, yb = (int64_t)p.M * ldn * esz;
-    MRFP_CHECK(xb < (int64_t)kOOB && yb < (int64_t)kOOB, "conv_wgrad: tensor exceeds the 3.75 GB buffer-descriptor range");
-    p.xbytes = (unsigned)xb; p.dybytes = (unsigned)yb;
+    p.Q = (int)(R * S * C);
+    // Both operands are read through 32-bit buffer-descriptor offsets: an activation above kOOB bytes is walked in batch
+    // ranges, every range one wgrad + reduction pair on the stream, the later ones adding to dw (fixed order: reproducible)
+    const int64_t ximg = H * W * C * esz, yimg = Ho * Wo * ldn * esz;
+    MRFP_CHECK(ximg < (int64_t)kOOB && yimg < (int64_t)kOOB, "conv_wgrad: one image exceeds the 3.75 GB buffer-descriptor range");
+    int64_t bmax = (int64_t)(kOOB - 1) / (ximg > yimg ? ximg : yimg);
+    int dbg_drop = 0;
     {   // timing-only diagnostics (see mrfp_conv_fwd)
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
-        if (dbg & 1) p.xbytes = 0;
-        if (dbg & 2) p.dybytes = 0;
+        dbg_drop = dbg;
     }
     p.div_hw = make_fastdiv((unsigned)(Ho * Wo)); p.div_w = make_fastdiv((unsigned)Wo);
-    int wm, splits;
-    wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen);
     hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st) : launch_wgrad<float, 2, 2>(p, splits, st);
-    else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st) : launch_wgrad<f16, 2, 2>(p, splits, st);
-    else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st) : launch_wgrad<bf16, 2, 2>(p, splits, st);
-    if (rc) return rc;
-    const int64_t total4 = N * (int64_t)p.Q / 4;          // Q = R*S*C and C*esz % 16 == 0  =>  Q % 4 == 0
-    int64_t blocks = (total4 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, splits, (int)N,
-                       p.Q, (int)C, (int)Ctrue, (int)(R * S), dw);
-    MRFP_LAUNCH_CHECK();
+    int wm0, cap, klen0;
+    wgrad_plan(B * Ho * Wo, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm0, cap, klen0);     // what `ws` was sized for
+    for (int64_t b0 = 0; b0 < B; b0 += bmax) {
+        const int64_t bc = B - b0 < bmax ? B - b0 : bmax;
+        p.B = (int)bc;
+        p.M = (int)(bc * Ho * Wo);
+        p.x = (const char*)x + b0 * ximg;
+        p.dy = (const char*)dy + b0 * yimg;
+        p.xbytes = (dbg_drop & 1) ? 0u : (unsigned)(bc * ximg);
+        p.dybytes = (dbg_drop & 2) ? 0u : (unsigned)(bc * yimg);
+        int wm, splits;
+        wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen, cap);
+        int rc;
+        if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st) : launch_wgrad<float, 2, 2>(p, splits, st);
+        else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st) : launch_wgrad<f16, 2, 2>(p, splits, st);
+        else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st) : launch_wgrad<bf16, 2, 2>(p, splits, st);
+        if (rc) return rc;
+        const int64_t total4 = N * (int64_t)p.Q / 4;          // Q = R*S*C and C*esz % 16 == 0  =>  Q % 4 == 0
+        int64_t blocks = (total4 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, splits, (int)N,
+                           p.Q, (int)C, (int)Ctrue, (int)(R * S), dw, b0 > 0 ? 1 : 0);
+        MRFP_LAUNCH_CHECK();
+    }
     return 0;
 }
 

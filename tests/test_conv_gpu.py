@@ -154,3 +154,40 @@ def test_alternative_tile_variants_in_subprocess():
         env = dict(os.environ, PYTHONPATH=root, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_activation_above_the_buffer_descriptor_range():
+    """One launch reads its input through 32-bit buffer-descriptor offsets (< 3.75 GB).  A larger activation --
+    BASELINE.json configs[4] at 16 images per GPU has a 4.3 GB one -- is walked in batch ranges by mrfp_conv_fwd /
+    mrfp_conv_wgrad themselves.  6 x 64 x 2432 x 2432 bf16 = 4.54 GB through a 1x1 convolution, forward + dgrad + wgrad,
+    against the same convolution run on the two halves of the batch (each below the limit; that path is checked against
+    torch above): forward and dgrad must be bit-identical, the weight gradient equal up to the split-K summation order."""
+    from mrfp_amd import _lib, conv
+    B, C, H, W, N = 6, 64, 2432, 2432, 64
+    assert B * C * H * W * 2 > 0xF0000000 and (B // 2) * C * H * W * 2 < 0xF0000000
+    assert _lib.lib().mrfp_conv_single_launch(B, C * H * W * 2) == 0 and _lib.lib().mrfp_conv_single_launch(B // 2, C * H * W * 2) == 1
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.empty(B, C, H, W, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.normal_(generator=g)
+    gy = torch.empty(B, N, H, W, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy.normal_(generator=g)
+    w = (torch.randn(N, C, 1, 1, device=DEV, generator=g) * 0.1)
+
+    def run(xs, gys):
+        xs = xs.detach().requires_grad_(True)
+        ws = w.detach().clone().requires_grad_(True)
+        y = conv.conv2d(xs, ws, None, 1, 0, 1)
+        y.backward(gys)
+        return y.detach(), xs.grad, ws.grad
+
+    y, dx, dw = run(x, gy)
+    h = B // 2
+    dws = []
+    for sl in (slice(0, h), slice(h, B)):
+        yh, dxh, dwh = run(x[sl], gy[sl])
+        assert torch.equal(y[sl], yh) and torch.equal(dx[sl], dxh)
+        dws.append(dwh)
+        del yh, dxh
+    ref = dws[0].double() + dws[1].double()
+    assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    assert torch.isfinite(dw).all() and dw.abs().max() > 0
