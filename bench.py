@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay zero_grad + forward + backward as a hipGraph (single GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--dump-convs", default=None, help="write per-launch conv shapes/timings (JSON) here")
+    ap.add_argument("--fourier", action="store_true", help="variant: also attach the build-defined multi-resolution Fourier "
+                    "amplitude perturbation (perturb.MultiResolutionFourier, every step) -- NOT the reference path, "
+                    "reported as its own workload")
     return ap.parse_args()
 
 
@@ -171,6 +174,9 @@ def main():
     model.load_state_dict(synth.synth_state_dict(synth.spec_of(model.state_dict()), seed=0))
     model = model.to(dev).train()
     model.rng = deepv3.InjectedRandom((True, True, True), None, reinit=True)   # all perturbations on, HRFP re-drawn
+    if args.fourier:
+        from mrfp_amd.perturb import MultiResolutionFourier
+        model.fourier_perturb = MultiResolutionFourier(p=1.0)
     trainer = Trainer(model)
     if args.graph:
         trainer.enable_graph()
@@ -210,9 +216,10 @@ def main():
         out = {"metric": "train images/sec", "value": round(value, 3), "unit": "images/sec", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "%s DeepLabV3+ + MRFP+ (HRFP+NP+ on, HRFP re-drawn every step), %dx%d, "
+               "config": {"workload": "%s DeepLabV3+ + MRFP+ (HRFP+NP+ on, HRFP re-drawn every step%s), %dx%d, "
                                       "%d images/GPU, fwd+bwd+SGD, synthetic 19-class, random-init weights"
-                                      % (args.trunk, args.size, width, args.batch),
+                                      % (args.trunk, ", + build-defined multi-resolution Fourier amplitude mix at stem/layer1/"
+                                         "layer2 every step" if args.fourier else "", args.size, width, args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "final_loss": round(lossv, 5)},
                "roofline": roof}

@@ -209,10 +209,12 @@ class _DeepLabBase(nn.Module):
             return self.layer1([t, w_arr])[0]
         return self.mod3(t)
 
-    def _high(self, t, w_arr):
+    def _high(self, t, w_arr, fourier=None):
         """low-level features -> ASPP input: layer2..layer4 (reference deepv3.py:338-344) / mod4..mod7 + bn_out."""
         if hasattr(self, "layer1"):
             t = self.layer2([t, w_arr])
+            if fourier is not None:
+                t[0] = fourier.at("layer2", t[0])
             self._tap("layer2", t[0])
             t = self.layer3(t)
             self._tap("layer3", t[0])
@@ -340,8 +342,15 @@ class MRFPPlus(_DeepLabBase):
             self.rng.reinit_hrfp(self)
 
         xp, w_arr = self._stem(x)
-        if training == True and self.fourier_perturb is not None:      # noqa: E712  (extension, default off)
-            xp = self.fourier_perturb(xp)
+        fourier = None
+        if training == True and self.fourier_perturb is not None:      # noqa: E712  (build-defined extension, default off)
+            fp = self.fourier_perturb
+            if hasattr(fp, "begin"):            # perturb.MultiResolutionFourier: stem, layer1 and layer2 resolutions
+                fp.begin(x.shape[0], True)
+                xp = fp.at("stem", xp)
+                fourier = fp
+            else:                               # a single perturb.FourierAmplitudeMix at the stem
+                xp = fp(xp)
         self._tap("stem", xp)
         OCout_dec, OCout, xp = self._hrfp(xp, h, w)   # always computed, as the reference does (no RNG inside)
         t = xp
@@ -351,11 +360,13 @@ class MRFPPlus(_DeepLabBase):
         if o1:
             t = ops.add(OCout, t)
         t = self._low(t, w_arr)
+        if fourier is not None:
+            t = fourier.at("layer1", t)
         if npp:
             t = self.Normalization_Perturbation_Plus(t, "np2")
         self._tap("layer1", t)
         dec0_fine, low_level = self.bot_fine.forward_skip(t)      # low-level features: decoder + layer2
-        t = self._high(low_level, w_arr)
+        t = self._high(low_level, w_arr, fourier)
         self._tap("layer4", t)
         t = self.aspp(t)
         self._tap("aspp", t)

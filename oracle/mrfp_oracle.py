@@ -303,7 +303,8 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
                  noise: Optional[Dict[str, Tensor]] = None,
                  new_stats: Optional[Dict[str, Tensor]] = None,
                  taps: Optional[dict] = None,
-                 perturb: bool = True):
+                 perturb: bool = True,
+                 fourier: Optional[dict] = None):
     """Functional MRFPPlus.forward (reference deepv3.py:280-367).
 
     toggles = (o1, npp, o2) = (p<0.5, p2<0.5, p3<0.5) of the reference; all three are
@@ -311,6 +312,9 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
     norm layers follow module mode = ``bn_train``, default = ``training``).
     noise = {'np1_alpha','np1_beta','np2_alpha','np2_beta'} normal draws for NP+.
     ``perturb=False`` gives simpleDeepV3Plus.forward (reference deepv3.py:451-490).
+    ``fourier`` = {"perm": LongTensor[B], "levels": {"stem"|"layer1"|"layer2": (radius, lam, high)}}: the BUILD-DEFINED
+    multi-resolution Fourier amplitude mix (no reference function: parity unpinned) applied after the stem, after layer1
+    (before the second NP+) and after layer2, only when ``training``.
     Returns the scalar loss when ``training`` else the logits."""
     if bn_train is None:
         bn_train = training
@@ -332,6 +336,13 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
     else:
         t = _resnet_stem(sd, x, norm)
     t = F.max_pool2d(t, 3, 2, 1)
+
+    def fmix(level, v):
+        if fourier is None or not training or level not in fourier["levels"]:
+            return v
+        r, lam, high = fourier["levels"][level]
+        return fourier_amplitude_mix(v, fourier["perm"], r, lam, high).to(v.dtype)
+    t = fmix("stem", t)
     xp = t
     taps["stem"] = xp
     if npp:
@@ -342,7 +353,7 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
         if o1:
             t = oc + t
     if wrn:
-        t = _wrn_module(sd, "mod3", t, bn_train, new_stats, noise)
+        t = fmix("layer1", _wrn_module(sd, "mod3", t, bn_train, new_stats, noise))
         if npp:
             t = np_plus(t, noise["np2_alpha"], noise["np2_beta"])
         low = t
@@ -358,11 +369,12 @@ def mrfp_forward(sd: Dict[str, Tensor], x: Tensor, gts: Optional[Tensor] = None,
     iw_l1 = 4 if "layer1.%d.instance_norm_layer.weight" % (nblk["layer1"] - 1) in sd else 0
     iw_l2 = 4 if "layer2.%d.instance_norm_layer.weight" % (nblk["layer2"] - 1) in sd else 0
     t = _stage(sd, "layer1", 64, nblk["layer1"], 1, 1, t, iw_l1, bn_train, new_stats)
+    t = fmix("layer1", t)
     if npp:
         t = np_plus(t, noise["np2_alpha"], noise["np2_beta"])
     low = t
     taps["layer1"] = low
-    t = _stage(sd, "layer2", 128, nblk["layer2"], 2, 1, t, iw_l2, bn_train, new_stats)
+    t = fmix("layer2", _stage(sd, "layer2", 128, nblk["layer2"], 2, 1, t, iw_l2, bn_train, new_stats))
     taps["layer2"] = t
     t = _stage(sd, "layer3", 256, nblk["layer3"], 2, 1, t, 0, bn_train, new_stats)
     taps["layer3"] = t
@@ -485,7 +497,7 @@ def fourier_amplitude_mix(x: Tensor, perm: Tensor, radius: float, lam: float = 1
     """y = irfft2(F * ratio) per (b, c) plane, F = rfft2(x); inside the selected band the amplitude becomes
     (1-lam)|F| + lam|F[perm]| with the phase of F; ratio is detached (no gradient through the amplitudes)."""
     B, C, H, W = x.shape
-    F_ = torch.fft.rfft2(x.float())
+    F_ = torch.fft.rfft2(x if x.dtype == torch.float64 else x.float())
     A = F_.abs()
     Ap = A[perm]
     kh = torch.arange(H)
