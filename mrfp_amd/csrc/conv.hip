@@ -782,8 +782,296 @@ static bool use_tile192(const ConvP& p, int esz) {
     const int nkt = (p.kchunks + 7) >> 3;
     return nkt >= 9 && ((p.M + 191) / 192) * ((p.N + 127) / 128) >= 2048;
 }
+
+// =============================================================================================
+// B-stationary kernel for the short-K 1x1 convolutions (16-bit types, K = C <= 256, stride 1): Y[M, N] = X[M, K] W[N, K]^T.
+//
+// The generic kernel re-fetches a 128-column weight tile with every 96..192-row tile (55..77 FLOP per byte of L2 -> LDS
+// fill, the path that bounds it, profiles/r02_experiments.md), and with 2-4 K tiles per workgroup its prologue / epilogue
+// weigh as much as its K loop (M = 36 864, 256 -> 1024: 412 TFLOP/s).  Here a workgroup is PERSISTENT over a range of
+// 64-row M tiles of one 128-column panel:
+//   * the weights never touch LDS: each wave keeps its 32 columns x K of the panel as MFMA B fragments in REGISTERS
+//     (K = 256: 64 VGPRs), loaded once per workgroup;
+//   * only X moves: a 64 x K tile per step, asynchronous LDS-DMA into a ring (counted vmcnt, one barrier per tile, the
+//     transfer of tile t + NST - 1 issued before tile t is multiplied), i.e. 128 instead of 55..77 FLOP per fill byte;
+//   * the MFMA runs transposed (accumulator rows = channels), so every lane stores 8 consecutive channels of a pixel
+//     straight from its accumulators: no transposition through LDS, no epilogue barrier; the optional fused per-channel
+//     statistics and skip-gradient addend of the generic kernel are kept.
+// Two workgroups per CU interleave one's epilogue with the other's multiplies.
+// Layout of an X tile in LDS: KB blocks of [64 rows][128 bytes], each with the generic kernel's XOR swizzle, so the
+// fragment reads are the generic kernel's (bank-conflict free).
+// =============================================================================================
+
+// two floats -> one dword of two 16-bit values (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: one instruction) and back
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+typedef __bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
+typedef _Float16 __attribute__((ext_vector_type(2))) f16x2_t;
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<bf16>(float a, float b) {
+    f32x2 v; v.x = a; v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <> __device__ __forceinline__ unsigned pack2<f16>(float a, float b) {
+    f32x2 v; v.x = a; v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+template <typename T> __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b);
+template <> __device__ __forceinline__ void unpack2<bf16>(unsigned w, float& a, float& b) {
+    a = __uint_as_float(w << 16);
+    b = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16>(unsigned w, float& a, float& b) {
+    const f32x2 v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2);
+    a = v.x;
+    b = v.y;
+}
+// sum over the 16 lanes of a DPP row (lanes 16q .. 16q + 15), result in every lane of the row; fixed order, VALU only
+// (__shfl_xor compiles to ds_bpermute_b32 + 4 address instructions per step)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
+    return v;
+}
+
+struct BsP {
+    const char* x;       // [M][K] dense (K = C elements)
+    const char* w;       // forward pack [N][K]
+    char* y;             // [M][ldy]
+    const char* addend;  // [M][ldy] or null
+    float* colstats;     // [ceil(M/64)][2][ldy] or null
+    int M, N, ldy;
+    int tiles;           // ceil(M / 64)
+    int panels;          // ceil(N / 128)
+    int chunks;          // M-tile ranges per panel (grid = panels * chunks)
+    unsigned xbytes, wbytes, ybytes;
+};
+
+template <typename T, int KB, int NST>
+__global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
+    constexpr int ROWB = KB * 128;              // bytes of one row of X (K elements)
+    constexpr int STAGE = KB * 64 * 128;        // one 64-row tile
+    constexpr int NP = KB * 2;                  // DMA pieces (8 rows x 128 B) per wave per tile: KB blocks x 8 pieces / 4 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: the DMA's LDS address (m0) must be uniform
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const i32x4 xw = rsrc_words(p.x, p.xbytes);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend ? p.addend : p.y), 0, (int)p.ybytes, 0x00020000);
+    // vmcnt bookkeeping: the output stores of a tile are issued AFTER the transfer of a later tile and are counted by the
+    // same in-order counter, so "tile t has landed" = all but the younger transfers AND the younger tiles' stores are
+    // done.  The stores are therefore UNCONDITIONAL buffer stores (rows / columns outside the tensor get an out-of-range
+    // offset and are dropped by the bounds check): exactly ST of them per wave per tile, whatever the tile covers.
+    constexpr int ST = 4;
+
+    // work: block b -> (chunk, panel) with the panels of one chunk (same rows of X) on one XCD (blocks b, b + 8, ... share an
+    // L2): b = xcd + 8 * (panel + panels * c2), chunk = xcd + 8 * c2
+    const int b = blockIdx.x, xcd = b & 7, rest = b >> 3;
+    const int panel = rest % p.panels, chunk = xcd + 8 * (rest / p.panels);
+    if (chunk >= p.chunks) return;              // (uniform per workgroup; no barrier has been passed yet)
+    const int per = (p.tiles + p.chunks - 1) / p.chunks;
+    const int t0 = chunk * per, t1 = min(p.tiles, t0 + per);
+    if (t0 >= t1) return;
+    const int n0 = panel * 128 + wave * 32;     // this wave's 32 columns
+
+    // ---- the weights: this wave's fragments for every K step, straight into registers ------------------------------------
+    // The MFMA runs TRANSPOSED (D = W_tile * X_tile^T: accumulator rows = output channels, columns = pixels), so a lane
+    // ends up with consecutive CHANNELS of one pixel and stores them directly -- no transposition of the result through
+    // LDS, no 2-byte LDS stores, no epilogue barrier.  Accumulator row r = 4*(lane>>4) + e of channel block j is mapped to
+    // channel 8*(r>>2) + 4*j + (r&3) of the wave's 32 columns (a permutation of the weight rows, free at load time): a
+    // lane's 2 x 4 values are then channels 8*(lane>>4) .. +7 of its pixel = one 16-byte store.
+    uint4 fw[KB * 2][2];                        // [k step of 32][channel block]
+#pragma unroll
+    for (int ks = 0; ks < KB * 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 8 * (l15 >> 2) + 4 * j + (l15 & 3);           // the channel accumulator row l15 of block j stands for
+            fw[ks][j] = bload(wr, n < p.N ? (unsigned)n * (unsigned)ROWB + (unsigned)(ks * 64 + lq * 16) : kOOB);
+        }
+
+    // ---- X tile DMA: piece q of this wave covers block kb = q / 2, rows (q & 1) * 32 + wave * 8 .. + 7 --------------------
+    unsigned src[NP], dst[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int kb = q >> 1, row = (q & 1) * 32 + wave * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);                     // source-side swizzle (LDS image is lane-linear)
+        src[q] = (unsigned)row * (unsigned)ROWB + (unsigned)(kb * 128 + ch * 16);
+        dst[q] = (unsigned)(kb * 64 * 128 + ((q & 1) * 32 + wave * 8) * 128);
+    }
+    auto issue = [&](int tile, int slot) {
+        const unsigned base = (unsigned)tile * 64u * (unsigned)ROWB;      // rows beyond M lie beyond xbytes: zero fill
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dma16_async(xw, lds0 + (unsigned)(slot * STAGE) + dst[q], base + src[q]);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (t0 + s < t1) issue(t0 + s, s);
+
+    const int nl = n0 + 8 * lq;                 // first of this lane's 8 output channels
+    float cs[8], cq[8];                         // per-channel sum / sum of squares over every tile of this workgroup
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { cs[u] = 0.f; cq[u] = 0.f; }
+    for (int tile = t0; tile < t1; ++tile) {
+        const int slot = (tile - t0) % NST;
+        // younger than the transfer of `tile`: NST-2 transfers and the stores of the NST-1 tiles multiplied since it was issued
+        if (tile - t0 >= NST - 1 && tile + NST - 1 <= t1) dma_wait<(NST - 2) * NP + (NST - 1) * ST>();
+        else dma_wait<0>();                                               // first / last tiles of the range: fewer behind it
+        __builtin_amdgcn_s_barrier();                                     // tile landed everywhere; tile - 1 fully consumed
+        // skip-gradient addend of this tile: fetched NOW (16 registers), consumed after the multiplies -- a load issued in
+        // the epilogue would be waited for right there, once per 16 pixels, with nothing else in this persistent workgroup
+        // to hide it (measured: dgrad launches 58 us against 32 us for the same shape without an addend)
+        const int m0 = tile * 64;
+        uint4 av[4];
+        if (p.addend) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i * 16 + l15;
+                av[i] = bload(ar, (m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB);
+            }
+        }
+        if (tile + NST - 1 < t1) issue(tile + NST - 1, (slot + NST - 1) % NST);
+
+        f32x4 acc[4][2];                        // [pixel block of 16][channel block]: rows = channels, columns = pixels
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+        const char* a = ring + slot * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KB * 2; ++ks) {
+            const char* ab = a + (ks >> 1) * (64 * 128);
+            const int ch = (ks & 1) * 4 + lq;
+            uint4 fx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fx[i] = *reinterpret_cast<const uint4*>(ab + lds_off(i * 16 + l15, ch));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma16<T>::run(acc[i][j], fw[ks][j], fx[i]);
+        }
+
+        // ---- epilogue of this tile, straight from the accumulators: lane = (pixel l15 of block i, channels nl .. nl + 7) ---
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i * 16 + l15;
+            const bool ok = m < p.M && nl < p.N;                          // (N % 8 == 0 for this kernel: chunks are whole)
+            uint4 v;
+            v.x = pack2<T>(acc[i][0][0], acc[i][0][1]);
+            v.y = pack2<T>(acc[i][0][2], acc[i][0][3]);
+            v.z = pack2<T>(acc[i][1][0], acc[i][1][1]);
+            v.w = pack2<T>(acc[i][1][2], acc[i][1][3]);
+            if (p.colstats) {
+                // statistics of the STORED (rounded) values, before the addend.  Rows beyond M were zero-filled by the
+                // transfer's bounds check, so they add exactly 0: no mask.
+                float f[8];
+                unpack2<T>(v.x, f[0], f[1]);
+                unpack2<T>(v.y, f[2], f[3]);
+                unpack2<T>(v.z, f[4], f[5]);
+                unpack2<T>(v.w, f[6], f[7]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    cs[u] += f[u];
+                    cq[u] += f[u] * f[u];
+                }
+            }
+            if (p.addend) v = chunk_add<T>(v, av[i]);                     // (loaded before the multiplies; complete by now)
+            const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
+            u32x4 dv;
+            dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
+            __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)off, 0, 0);
+        }
+    }
+    if (p.colstats) {
+        // ONE statistics row block per workgroup range (all its tiles): the 16 lanes of a quarter hold the same 8 channels
+        // for 16 different pixels -- fold them (DPP, fixed order) and let lane 0 of the quarter write
+        float* out = p.colstats + (size_t)chunk * 2 * p.ldy;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            cs[u] = row16_sum(cs[u]);
+            cq[u] = row16_sum(cq[u]);
+        }
+        if (l15 == 0 && nl < p.N) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                out[nl + u] = cs[u];
+                out[p.ldy + nl + u] = cq[u];
+            }
+        }
+    }
+}
+
+static int g_bstat = -1;
+// the layers the B-stationary kernel takes (MRFP_CONV_BSTAT=0: generic kernel everywhere, for A/B runs)
+static bool use_bstat(const ConvP& p, int esz, bool has_bias) {
+    if (g_bstat < 0) {
+        const char* e = getenv("MRFP_CONV_BSTAT");
+        g_bstat = e ? atoi(e) : 1;
+    }
+    if (!g_bstat || esz != 2 || has_bias || p.bnx) return false;
+    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.sstride != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
+    if (p.Ho != p.H || p.Wo != p.W || p.N < 128 || (p.N & 7) != 0) return false;
+    if ((int64_t)p.M * p.ldy * esz >= (int64_t)kOOB) return false;        // the output is addressed through a buffer descriptor
+    const int rowb = p.C * esz;
+    return rowb == 128 || rowb == 256 || rowb == 512;
+}
+
+// M-tile ranges per panel: two workgroups per CU, each at least 4 tiles long (the weights are loaded once per workgroup),
+// a multiple of 8 (the XCD mapping), and no range empty.  Also the number of statistics row blocks of such a launch.
+static int bstat_chunks(int M, int N) {
+    const int tiles = (M + 63) / 64, panels = (N + 127) / 128;
+    int chunks = 512 / panels;
+    while (chunks > 8 && (tiles + chunks - 1) / chunks < 4) chunks -= 8;
+    chunks = (chunks + 7) / 8 * 8;
+    if (chunks < 8) chunks = 8;
+    const int per = (tiles + chunks - 1) / chunks;
+    return (tiles + per - 1) / per;              // ranges that actually hold tiles (the trailing ones would be empty)
+}
+
+template <typename T, int KB>
+static int launch_bstat(const ConvP& c, hipStream_t st) {
+    constexpr int NST = KB == 4 ? 2 : 3;                          // K = 256: 2 x 32 KB stages (two workgroups per CU)
+    constexpr int STAGE = KB * 64 * 128;
+    const int lds = NST * STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bstat_kernel<T, KB, NST>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    BsP p;
+    p.x = c.x; p.w = c.w; p.y = c.y; p.addend = c.addend; p.colstats = c.colstats;
+    p.M = c.M; p.N = c.N; p.ldy = c.ldy;
+    p.tiles = (c.M + 63) / 64;
+    p.panels = (c.N + 127) / 128;
+    p.chunks = bstat_chunks(c.M, c.N);
+    const int chunks = (p.chunks + 7) / 8 * 8;           // grid: whole groups of 8 (workgroups past p.chunks exit at once)
+    p.xbytes = c.xbytes; p.wbytes = c.wbytes; p.ybytes = (unsigned)((int64_t)c.M * c.ldy * 2);
+    {   // timing-only diagnostics (MRFP_DEBUG_DROP bit 2: drop the output stores)
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
+        if (dbg & 4) p.ybytes = 0;
+    }
+    hipLaunchKernelGGL((conv1x1_bstat_kernel<T, KB, NST>), dim3((unsigned)(p.panels * chunks)), dim3(256), lds, st, p);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int run_bstat(const ConvP& p, hipStream_t st) {
+    const int kb = p.C * 2 / 128;
+    return kb == 1 ? launch_bstat<T, 1>(p, st) : kb == 2 ? launch_bstat<T, 2>(p, st) : launch_bstat<T, 4>(p, st);
+}
+
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
 static int64_t stats_row_blocks(const ConvP& p, int esz) {
+    if (use_bstat(p, esz, false)) return (int64_t)bstat_chunks(p.M, p.N);               // conv1x1_bstat_kernel: one per workgroup range
     if (p.N > 64 && use_tile192(p, esz)) return (int64_t)((p.M + 191) / 192) * 2;      // <2,2,3,2>: 192-row tile, 2 wave rows
     if (p.N <= 64) return (int64_t)((p.M + 255) / 256) * 4;          // <4,1,2,2>: 256-row tile, 4 wave rows
     if (use_big_tile(p, esz)) return (int64_t)((p.M + 255) / 256) * 2;  // <2,4,4,2>: 256-row tile, 2 wave rows
@@ -793,6 +1081,9 @@ static int64_t stats_row_blocks(const ConvP& p, int esz) {
 
 template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (use_bstat(p, 2, p.bias != nullptr)) return run_bstat<T>(p, st);
+    }
     if (p.N <= 64) return pick_igemm<T, 4, 1, 2, 2>(p, st);
     // 256x256 tile (8 waves x 128x64, LDS-DMA, one workgroup per CU).  Measured per shape on MI355X inside the
     // bench workload (bench.py --dump-convs): +8..10 % on long-K 3x3 layers with >= 2 full rounds of tiles
@@ -1014,10 +1305,13 @@ int mrfp_conv_dgrad_bnstats(const void* dy, const void* wpack, void* dx, int dty
                          bnstats, bn_x, bn_y, bn_mean, bn_fA, bn_fS, stream);
 }
 
-int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S) {
+int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S, int64_t pointwise) {
     ConvP p;
     const int esz = dtype == MRFP_F32 ? 4 : 2;
-    p.M = (int)M; p.N = (int)N; p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    p.M = (int)M; p.N = (int)N; p.ldy = (int)N; p.C = (int)C; p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    // what the kernel choice looks at besides the sizes: `pointwise` = 1x1, stride 1, no padding, output size = input size
+    p.R = (int)R; p.S = (int)S; p.stride = pointwise ? 1 : 2; p.sstride = 1; p.pad_h = p.pad_w = 0;
+    p.H = p.W = p.Ho = p.Wo = 1; p.bnx = nullptr; p.bias = nullptr;
     return stats_row_blocks(p, esz);
 }
 /* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */

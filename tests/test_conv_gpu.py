@@ -30,6 +30,14 @@ CASES = [
     (2, 128, 240, 236, 256, 3, 1, 2, 2, False),  # 256x256 tile, dilated, ragged M
     (2, 1152, 244, 240, 256, 1, 1, 0, 1, False), # 256x256 tile on a 1x1 conv with 18 K tiles
     (2, 304, 240, 240, 256, 3, 1, 1, 1, False),  # big tile with taps straddling K tiles (304 channels)
+    # the B-stationary kernel (16-bit types, pointwise, C in {64, 128, 256}, N >= 128): every K depth, ragged M (not a
+    # multiple of the 64-row tile), N that ends inside a 128-column panel / inside a 16-column block, one-tile problems
+    (2, 64, 20, 18, 256, 1, 1, 0, 1, False),
+    (3, 128, 33, 31, 512, 1, 1, 0, 1, False),
+    (2, 256, 24, 24, 1024, 1, 1, 0, 1, False),
+    (1, 256, 7, 9, 136, 1, 1, 0, 1, False),
+    (2, 128, 96, 96, 200, 1, 1, 0, 1, False),
+    (4, 256, 48, 48, 1024, 1, 1, 0, 1, False),   # several tiles per workgroup: the ring wraps
 ]
 
 
