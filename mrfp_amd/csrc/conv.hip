@@ -96,6 +96,14 @@ constexpr bool kM16 = MRFP_M16 != 0;
 #ifndef MRFP_WIDE_EP
 #define MRFP_WIDE_EP 1
 #endif
+// MRFP_TR (build switch, default OFF, 16-bit types): transposed MFMA + direct 16-byte channel stores in the forward / dgrad
+// epilogue instead of the LDS transposition (see TR in conv_igemm_kernel).  It is what makes the persistent B-stationary
+// kernel fast (no other workgroup hides its epilogue), but in the generic kernel the co-resident workgroups already do, and
+// the 64-byte store runs lose to the wide layout's 256-byte runs: 60.78 vs 60.42 ms per bench step over three alternations
+// on one box (`tools/build_variant.sh tr conv -DMRFP_TR=1`, tools/ab_lib.sh).
+#ifndef MRFP_TR
+#define MRFP_TR 0
+#endif
 constexpr bool kWideEp = MRFP_WIDE_EP != 0;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <typename T> struct Mma16 {
@@ -111,6 +119,41 @@ template <> struct Mma16<f16> {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
     }
 };
+
+// two floats -> one dword of two 16-bit values (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: one instruction) and back
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+typedef __bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
+typedef _Float16 __attribute__((ext_vector_type(2))) f16x2_t;
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<bf16>(float a, float b) {
+    f32x2 v; v.x = a; v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <> __device__ __forceinline__ unsigned pack2<f16>(float a, float b) {
+    f32x2 v; v.x = a; v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+template <typename T> __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b);
+template <> __device__ __forceinline__ void unpack2<bf16>(unsigned w, float& a, float& b) {
+    a = __uint_as_float(w << 16);
+    b = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16>(unsigned w, float& a, float& b) {
+    const f32x2 v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2);
+    a = v.x;
+    b = v.y;
+}
+// sum over the 16 lanes of a DPP row (lanes 16q .. 16q + 15), result in every lane of the row; fixed order, VALU only
+// (__shfl_xor compiles to ds_bpermute_b32 + 4 address instructions per step)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
+    return v;
+}
+template <> __device__ __forceinline__ unsigned pack2<float>(float a, float) { return __float_as_uint(a); }   // (unused: 16-bit epilogue only)
+template <> __device__ __forceinline__ void unpack2<float>(unsigned w, float& a, float& b) { a = __uint_as_float(w); b = 0.f; }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
 
@@ -350,6 +393,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
     };
 
     constexpr bool M16 = kM16 && sizeof(T) == 2;
+    // TR: the 16x16x32 MFMAs run TRANSPOSED (D = W_tile * X_tile^T: accumulator rows = output channels, columns = pixels) so
+    // that a lane ends up with 8 consecutive CHANNELS of one pixel and stores them straight from its registers -- no
+    // transposition of the result through LDS, no 2-byte LDS stores, no epilogue barrier (the epilogue's instruction count,
+    // not its bytes, is what the short-K layers pay for: profiles/r02_experiments.md section 3).  Accumulator row r of
+    // channel block j stands for channel 32*(j>>1) + 8*(r>>2) + 4*(j&1) + (r&3) of the wave's columns (a permutation of the
+    // weight-tile rows, applied in the fragment read address).
+    constexpr bool TR = M16 && !BNB && MRFP_TR != 0;
     f32x16 acc[TM][TN];
     f32x4 acc16[2 * TM][2 * TN];       // M16: 16x16 blocks, D[row = 4*(lane>>4) + e][col = lane&15]
 #pragma unroll
@@ -380,11 +430,17 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
 #pragma unroll
                 for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(a + lds_off(wm * 32 * TM + i * 16 + l15, ch));
 #pragma unroll
-                for (int j = 0; j < 2 * TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 32 * TN + j * 16 + l15, ch));
+                for (int j = 0; j < 2 * TN; ++j) {
+                    const int brow = TR ? 32 * (j >> 1) + 8 * (l15 >> 2) + 4 * (j & 1) + (l15 & 3) : j * 16 + l15;
+                    fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 32 * TN + brow, ch));
+                }
 #pragma unroll
                 for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2 * TN; ++j) Mma16<T>::run(acc16[i][j], fa[i], fb[j]);
+                    for (int j = 0; j < 2 * TN; ++j) {
+                        if constexpr (TR) Mma16<T>::run(acc16[i][j], fb[j], fa[i]);
+                        else Mma16<T>::run(acc16[i][j], fa[i], fb[j]);
+                    }
             }
             return;
         }
@@ -451,6 +507,88 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
         }
     }
 
+    if constexpr (TR) {
+        // ---- direct epilogue: lane (lq = lane>>4, l15 = lane&15) holds, for pixel block ib and channel pair P, the 8 channels
+        // nb + 32 P + 8 lq .. + 7 of pixel m0 + wm*32*TM + 16 ib + l15: bias, statistics, addend and ONE 16-byte store.
+        T* const yT = reinterpret_cast<T*>(p.y);
+        const int nbw = n0 + wn * 32 * TN;
+        float bvp[TN][8], cs8[TN][8], cq8[TN][8];
+#pragma unroll
+        for (int P = 0; P < TN; ++P)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = nbw + 32 * P + 8 * lq + u;
+                bvp[P][u] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+                cs8[P][u] = 0.f;
+                cq8[P][u] = 0.f;
+            }
+#pragma unroll
+        for (int ib = 0; ib < 2 * TM; ++ib) {
+            const int m = m0 + wm * 32 * TM + ib * 16 + l15;
+#pragma unroll
+            for (int P = 0; P < TN; ++P) {
+                const int n = nbw + 32 * P + 8 * lq;
+                uint4 v;
+                v.x = pack2<T>(acc16[ib][2 * P][0] + bvp[P][0], acc16[ib][2 * P][1] + bvp[P][1]);
+                v.y = pack2<T>(acc16[ib][2 * P][2] + bvp[P][2], acc16[ib][2 * P][3] + bvp[P][3]);
+                v.z = pack2<T>(acc16[ib][2 * P + 1][0] + bvp[P][4], acc16[ib][2 * P + 1][1] + bvp[P][5]);
+                v.w = pack2<T>(acc16[ib][2 * P + 1][2] + bvp[P][6], acc16[ib][2 * P + 1][3] + bvp[P][7]);
+                if (p.colstats) {       // BatchNorm statistics of the STORED (rounded) values, fused into the producer
+                    float f[8];
+                    unpack2<T>(v.x, f[0], f[1]);
+                    unpack2<T>(v.y, f[2], f[3]);
+                    unpack2<T>(v.z, f[4], f[5]);
+                    unpack2<T>(v.w, f[6], f[7]);
+                    const float live = m < p.M ? 1.f : 0.f;       // (rows beyond M hold 0 + bias)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float fv = f[u] * live;
+                        cs8[P][u] += fv;
+                        cq8[P][u] += fv * fv;
+                    }
+                }
+                if (m < p.M && n < p.N) {
+                    T* dst = yT + (size_t)m * p.ldy + n;
+                    const bool full = n + 8 <= p.N;
+                    if (p.addend) {      // y += addend (the skip-connection gradient)
+                        const T* ad = reinterpret_cast<const T*>(p.addend) + (size_t)m * p.ldy + n;
+                        uint4 av = make_uint4(0u, 0u, 0u, 0u);
+                        if (full) {
+                            av = *reinterpret_cast<const uint4*>(ad);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (n + u < p.N) chunk_set<T>(av, u, ad[u]);
+                        }
+                        v = chunk_add<T>(v, av);
+                    }
+                    if (full) {
+                        *reinterpret_cast<uint4*>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (n + u < p.N) dst[u] = chunk_get<T>(v, u);
+                    }
+                }
+            }
+        }
+        if (p.colstats) {
+            // the 16 lanes of a quarter hold the same channels for 16 different pixels: fold them (DPP, fixed order)
+            float* out = p.colstats + (size_t)((tile / ntn) * WM + wm) * 2 * p.ldy;
+#pragma unroll
+            for (int P = 0; P < TN; ++P)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float s2 = row16_sum(cs8[P][u]), q2 = row16_sum(cq8[P][u]);
+                    const int n = nbw + 32 * P + 8 * lq + u;
+                    if (l15 == 0 && n < p.N) {
+                        out[n] = s2;
+                        out[p.ldy + n] = q2;
+                    }
+                }
+        }
+        return;
+    }
     // epilogue.  MFMA 32x32 accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31], i.e. a
     // lane owns single elements of 16 rows -- storing that directly is 2-byte scattered traffic.  Instead every
     // wave transposes its tile through LDS (free after the K loop) 32 rows at a time and writes whole 16-byte
@@ -801,39 +939,6 @@ static bool use_tile192(const ConvP& p, int esz) {
 // Layout of an X tile in LDS: KB blocks of [64 rows][128 bytes], each with the generic kernel's XOR swizzle, so the
 // fragment reads are the generic kernel's (bank-conflict free).
 // =============================================================================================
-
-// two floats -> one dword of two 16-bit values (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: one instruction) and back
-typedef float __attribute__((ext_vector_type(2))) f32x2;
-typedef __bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
-typedef _Float16 __attribute__((ext_vector_type(2))) f16x2_t;
-template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
-template <> __device__ __forceinline__ unsigned pack2<bf16>(float a, float b) {
-    f32x2 v; v.x = a; v.y = b;
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-template <> __device__ __forceinline__ unsigned pack2<f16>(float a, float b) {
-    f32x2 v; v.x = a; v.y = b;
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
-}
-template <typename T> __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b);
-template <> __device__ __forceinline__ void unpack2<bf16>(unsigned w, float& a, float& b) {
-    a = __uint_as_float(w << 16);
-    b = __uint_as_float(w & 0xffff0000u);
-}
-template <> __device__ __forceinline__ void unpack2<f16>(unsigned w, float& a, float& b) {
-    const f32x2 v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2);
-    a = v.x;
-    b = v.y;
-}
-// sum over the 16 lanes of a DPP row (lanes 16q .. 16q + 15), result in every lane of the row; fixed order, VALU only
-// (__shfl_xor compiles to ds_bpermute_b32 + 4 address instructions per step)
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
-    return v;
-}
 
 struct BsP {
     const char* x;       // [M][K] dense (K = C elements)
