@@ -202,19 +202,6 @@ template <int N> __device__ __forceinline__ void dma_wait() {      // all but th
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-// A 16-byte global load into registers that the compiler does not track (same reason as dma16_async: a load it tracks makes
-// it place `s_waitcnt vmcnt(k)` with k computed from ITS count of outstanding operations, which forces the untracked LDS-DMA
-// transfers of the next tile to land as well).  The consumer must pass the registers through loaded_wait<N>() first.
-__device__ __forceinline__ u32x4 bload_async(const i32x4& rsrc, unsigned voff) {
-    u32x4 r;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc));
-    return r;
-}
-template <int N> __device__ __forceinline__ void loaded_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-    // all but the N youngest vector-memory operations are done; the four registers are tied to the wait, so no use of
-    // them can be scheduled in front of it
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
 __device__ __forceinline__ void settle(uint4& v) {      // forces the compiler to wait for a tracked load right here
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
@@ -984,7 +971,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     const i32x4 xw = rsrc_words(p.x, p.xbytes);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.ybytes, 0x00020000);
-    const i32x4 aw = rsrc_words(p.addend ? p.addend : p.y, p.ybytes);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend ? p.addend : p.y), 0, (int)p.ybytes, 0x00020000);
     // vmcnt bookkeeping: the output stores of a tile are issued AFTER the transfer of a later tile and are counted by the
     // same in-order counter, so "tile t has landed" = all but the younger transfers AND the younger tiles' stores are
     // done.  The stores are therefore UNCONDITIONAL buffer stores (rows / columns outside the tensor get an out-of-range
@@ -1055,16 +1042,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         // the epilogue would be waited for right there, once per 16 pixels, with nothing else in this persistent workgroup
         // to hide it (measured: dgrad launches 58 us against 32 us for the same shape without an addend)
         const int m0 = tile * 64;
-        u32x4 av[4];
+        // (a compiler-tracked load: its wait in the epilogue also drains the transfers issued below -- they have had the
+        //  whole multiply phase to land.  An untracked inline-asm load with a counted wait was tried and is WRONG: the
+        //  compiler may copy the destination registers before the data has arrived -- the bitwise-reproducibility test
+        //  caught it.)
+        uint4 av[4];
         if (p.addend) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + i * 16 + l15;
-                av[i] = bload_async(aw, (m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB);
+                av[i] = bload(ar, (m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB);
             }
         }
-        const bool issued = tile + NST - 1 < t1;
-        if (issued) issue(tile + NST - 1, (slot + NST - 1) % NST);
+        if (tile + NST - 1 < t1) issue(tile + NST - 1, (slot + NST - 1) % NST);
 
         f32x4 acc[4][2];                        // [pixel block of 16][channel block]: rows = channels, columns = pixels
 #pragma unroll
@@ -1088,10 +1078,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         }
 
         // ---- epilogue of this tile, straight from the accumulators: lane = (pixel l15 of block i, channels nl .. nl + 7) ---
-        if (p.addend) {                                                   // the addend has landed; the NP transfers issued
-            if (issued) loaded_wait<NP>(av[0], av[1], av[2], av[3]);      // after it may still be in flight
-            else loaded_wait<0>(av[0], av[1], av[2], av[3]);
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + i * 16 + l15;
@@ -1115,7 +1101,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
                     cq[u] += f[u] * f[u];
                 }
             }
-            if (p.addend) v = chunk_add<T>(v, make_uint4(av[i].x, av[i].y, av[i].z, av[i].w));
+            if (p.addend) v = chunk_add<T>(v, av[i]);                     // (loaded before the multiplies)
             const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
             u32x4 dv;
             dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
