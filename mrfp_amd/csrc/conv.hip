@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     for (int s = 0; s < NST - 1; ++s)
         if (t0 + s < t1) issue(t0 + s, s);
 
+    // (a half-tile start delay for the second resident workgroup of every CU was measured: no effect)
     const int nl = n0 + 8 * lq;                 // first of this lane's 8 output channels
     float cs[8], cq[8];                         // per-channel sum / sum of squares over every tile of this workgroup
 #pragma unroll
