@@ -42,6 +42,7 @@ struct ConvP {
     // statistics  sum g'  and  sum g' * (x - mean)  with  g' = g * [ReLU mask]  are produced here, per row block, instead
     // of by a separate pass over (g, x):  bnx = BN input [M][ldy], bny = BN output for the mask (residual blocks) or null,
     // bnA / bnS = forward apply coefficients for the recomputed mask (x*A+S > 0) or null (no ReLU), bnmean [ldy].
+    int stagger8;       // 8-wave tile: waves 4-7 issue their transfers between the two halves of the multiply
     const char* bnx;
     const char* bny;
     const float* bnmean;
@@ -270,6 +271,7 @@ template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a,
 
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
+    const bool g_stagger8 = p.stagger8 != 0;
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -423,12 +425,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
     uint4 ra[SA], rb[SB];
     const int lr = lane & 31, lh = lane >> 5;
     const int l15 = lane & 15, lq = lane >> 4;
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int kk0 = 0, int kk1 = 2) {
         const char* a = sA0 + buf * BUF;
         const char* b = sB0 + buf * BUF;
         if constexpr (M16) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {          // K step 32 = 4 chunks, one per lane quarter
+            for (int kk = kk0; kk < kk1; ++kk) {      // K step 32 = 4 chunks, one per lane quarter
                 const int ch = kk * 4 + lq;
                 uint4 fa[2 * TM], fb[2 * TN];
 #pragma unroll
@@ -471,6 +473,70 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
             compute(0);
             __syncthreads();          // everybody is done reading before the next fill
         }
+    } else if constexpr (DMA && NBUF == 2 && WM * WN == 8 && M16) {
+        // ---- 8-wave tile, PING-PONG: the two waves of every SIMD (wave w and w + 4) alternate roles phase by phase -- one
+        // multiplies from fragments already in its registers while the other reads its next fragments from LDS and issues
+        // its LDS-DMA transfers -- so the matrix pipe of a SIMD always has exactly one wave feeding it, instead of both
+        // waves multiplying together and then both stalling together (lock-step after the barrier: the round-1 / async-ring
+        // variants of this tile, 984 TFLOP/s; a plain half-step stagger already gave +5 %).  One work item = half a K tile
+        // (one k step of 32); group X (waves 0-3) reads item i in phase 2i and multiplies it in phase 2i+1, group Y (waves
+        // 4-7) one phase later; one s_barrier per phase.  K tile kt sits in slot kt & 1 and is read in phases 4kt .. 4kt+3;
+        // tile kt+1 is issued in phases 4kt (X) / 4kt+1 (Y) into the slot tile kt-1 left in phase 4kt-1, every wave waits
+        // for its own pieces at the end of phase 4kt+3 (vmcnt(0): issued 2-3 phases earlier), and the barrier that opens
+        // phase 4kt+4 publishes them.
+        const bool grpY = wave >= 4;
+        uint4 fa[2 * TM], fb[2 * TN];
+        auto read_frags = [&](int buf, int kk) {
+            const char* a = sA0 + buf * BUF;
+            const char* b = sB0 + buf * BUF;
+            const int ch = kk * 4 + lq;
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(a + lds_off(wm * 32 * TM + i * 16 + l15, ch));
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) {
+                const int brow = TR ? 32 * (j >> 1) + 8 * (l15 >> 2) + 4 * (j & 1) + (l15 & 3) : j * 16 + l15;
+                fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 32 * TN + brow, ch));
+            }
+        };
+        auto mma_frags = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2 * TN; ++j) {
+                    if constexpr (TR) Mma16<T>::run(acc16[i][j], fb[j], fa[i]);
+                    else Mma16<T>::run(acc16[i][j], fa[i], fb[j]);
+                }
+        };
+        load_tile(0, ra, rb, 0);
+        dma_wait<0>();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            const bool more = kt + 1 < nkt && p.stagger8 != 2;      // (stagger8 == 2: timing experiment, no transfers issued)
+            __builtin_amdgcn_s_barrier();                     // phase 4kt
+            if (!grpY) {
+                read_frags(buf, 0);
+                if (more) load_tile(kt + 1, ra, rb, buf ^ 1);
+            } else if (kt > 0) {
+                mma_frags();                                  // item (kt-1, 1)
+            }
+            __builtin_amdgcn_s_barrier();                     // phase 4kt+1
+            if (!grpY) {
+                mma_frags();
+            } else {
+                read_frags(buf, 0);
+                if (more) load_tile(kt + 1, ra, rb, buf ^ 1);
+            }
+            __builtin_amdgcn_s_barrier();                     // phase 4kt+2
+            if (!grpY) read_frags(buf, 1);
+            else mma_frags();
+            __builtin_amdgcn_s_barrier();                     // phase 4kt+3
+            if (!grpY) mma_frags();
+            else read_frags(buf, 1);
+            dma_wait<0>();                                    // this wave's pieces of tile kt+1 have landed
+        }
+        __builtin_amdgcn_s_barrier();                         // phase 4 nkt: Y multiplies its last item
+        if (grpY) mma_frags();
+        __builtin_amdgcn_s_barrier();                         // everybody is done reading the ring: the epilogue reuses it
     } else if constexpr (DMA) {
         // NBUF-stage LDS ring, NBUF-1 K tiles in flight per workgroup.  Iteration kt: wait until this wave's pieces of
         // tile kt have landed (all but the (NBUF-2)*NP youngest transfers), barrier (everybody's have, and everybody has
@@ -485,8 +551,17 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
             if (kt + NBUF - 1 <= nkt) dma_wait<(NBUF - 2) * NP>();      // NBUF-2 younger tiles may still be in flight
             else dma_wait<0>();                                        // tail: fewer tiles behind this one
             __builtin_amdgcn_s_barrier();
-            if (kt + NBUF - 1 < nkt) load_tile(kt + NBUF - 1, ra, rb, (kt + NBUF - 1) % NBUF);
-            compute(kt % NBUF);
+            // 8-wave tile (two waves per SIMD, same program): waves 4-7 issue their transfers BETWEEN the two halves of the
+            // multiply, so a SIMD's two waves are not both in their (MFMA-free) issue phase right after the barrier
+            // (MI355X_MICROARCH.md, two waves per SIMD, item 9: stagger by wave number >= 4)
+            if (WM * WN == 8 && M16 && g_stagger8 && wave >= 4) {
+                compute(kt % NBUF, 0, 1);
+                if (kt + NBUF - 1 < nkt) load_tile(kt + NBUF - 1, ra, rb, (kt + NBUF - 1) % NBUF);
+                compute(kt % NBUF, 1, 2);
+            } else {
+                if (kt + NBUF - 1 < nkt) load_tile(kt + NBUF - 1, ra, rb, (kt + NBUF - 1) % NBUF);
+                compute(kt % NBUF);
+            }
         }
         dma_wait<0>();
         __builtin_amdgcn_s_barrier();             // everybody is done reading the ring: the epilogue reuses it
@@ -1344,6 +1419,11 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
     MRFP_CHECK(aligned16(x) && aligned16(wpack), "conv_fwd: x / wpack must be 16-byte aligned");
     MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_fwd: tensor too large for 32-bit tile indices");
     ConvP p;
+    {
+        static int stg = -1;
+        if (stg < 0) { const char* e = getenv("MRFP_CONV_STAGGER8"); stg = e ? atoi(e) : 1; }
+        p.stagger8 = stg;
+    }
     p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias; p.addend = (const char*)addend; p.colstats = colstats;
     p.bnx = (const char*)bnx; p.bny = (const char*)bny; p.bnmean = bnmean; p.bnA = bnA; p.bnS = bnS;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
