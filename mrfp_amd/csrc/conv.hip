@@ -1682,7 +1682,11 @@ template <> struct WgFrag<float> {
 template <typename T> struct WgTile { static constexpr int BKP = 64; };   // pixels per K' tile
 template <> struct WgTile<float> { static constexpr int BKP = 32; };
 
-template <typename T, int WM, int WN, bool DMA>
+// DENSE: pointwise convolution (1x1, stride 1, no padding): X is a dense [pixel][channel] matrix like dY, so its slots advance
+// by a constant and need no (ih, iw) bookkeeping -- 60 of the 85 VALU and 40 of the 64 SALU instructions of a K' tile in
+// the general kernel, on layers (M = 36 864 bottleneck 1x1) that are bound by exactly that instruction stream
+// (profiles/r02_experiments.md section 4: 31 us with or without any global traffic, MFMA time 11 us).
+template <typename T, int WM, int WN, bool DMA, bool DENSE = false>
 __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {   // 2nd = waves per SIMD
     static_assert(WM * WN == 4, "4 waves");
     static_assert(!DMA || sizeof(T) == 2, "LDS-DMA layout is for the 16-bit types");
@@ -1740,12 +1744,19 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
 #pragma unroll
     for (int i = 0; i < SX; ++i) {
         const int m = kbeg + xrow + i * (256 / CX);
-        const int b = m / (p.Ho * p.Wo), rem = m - b * (p.Ho * p.Wo);
-        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-        x_ih[i] = oh * st + dh;
-        x_iw[i] = ow * st + dw;
-        x_off[i] = (unsigned)((b * p.H + x_ih[i]) * p.W + x_iw[i]) * (unsigned)pixbytes + (unsigned)c * (unsigned)sizeof(T);
+        if constexpr (DENSE) {
+            x_ih[i] = 0;
+            x_iw[i] = 0;
+            x_off[i] = (unsigned)m * (unsigned)pixbytes + (unsigned)c * (unsigned)sizeof(T);
+        } else {
+            const int b = m / (p.Ho * p.Wo), rem = m - b * (p.Ho * p.Wo);
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            x_ih[i] = oh * st + dh;
+            x_iw[i] = ow * st + dw;
+            x_off[i] = (unsigned)((b * p.H + x_ih[i]) * p.W + x_iw[i]) * (unsigned)pixbytes + (unsigned)c * (unsigned)sizeof(T);
+        }
     }
+    const unsigned x_step = (unsigned)BKP * (unsigned)pixbytes;
     unsigned y_off[SY];
 #pragma unroll
     for (int i = 0; i < SY; ++i) y_off[i] = (unsigned)(kbeg + yrow + i * (256 / CY)) * yrowbytes + ycol;
@@ -1765,18 +1776,23 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
 #pragma unroll
         for (int i = 0; i < SX; ++i) {
             const int m = k0 + xrow + i * (256 / CX);
-            const bool ok = xcol_ok && m < kend && (unsigned)x_ih[i] < (unsigned)p.H && (unsigned)x_iw[i] < (unsigned)p.W;
+            const bool ok = DENSE ? (xcol_ok && m < kend)
+                                  : (xcol_ok && m < kend && (unsigned)x_ih[i] < (unsigned)p.H && (unsigned)x_iw[i] < (unsigned)p.W);
             if (DMA)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(tx + (wave1k + i * 4096)), 16,
                                                          (int)(ok ? x_off[i] : kOOB), 0, 0, 0);
             else
                 rx[i] = bload(xr, ok ? x_off[i] : kOOB);
             // advance this slot by one K' tile
-            x_iw[i] += d_iw;
-            x_ih[i] += d_ih;
-            x_off[i] += D0;
-            if (x_iw[i] >= iw_lim) { x_iw[i] -= WoSt; x_ih[i] += st; x_off[i] += D1; }
-            while (x_ih[i] >= ih_lim) { x_ih[i] -= HoSt; x_off[i] += D2; }
+            if constexpr (DENSE) {
+                x_off[i] += x_step;
+            } else {
+                x_iw[i] += d_iw;
+                x_ih[i] += d_ih;
+                x_off[i] += D0;
+                if (x_iw[i] >= iw_lim) { x_iw[i] -= WoSt; x_ih[i] += st; x_off[i] += D1; }
+                while (x_ih[i] >= ih_lim) { x_ih[i] -= HoSt; x_off[i] += D2; }
+            }
         }
     };
     auto store_tile = [&](const uint4 (&ry)[SY], const uint4 (&rx)[SX]) {
@@ -1890,19 +1906,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
     }
 }
 
-template <typename T, int WM, int WN, bool DMA>
+template <typename T, int WM, int WN, bool DMA, bool DENSE = false>
 static int launch_wgrad_v(const WgP& p, int splits, hipStream_t st) {
     constexpr int PY = 64 * WM * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);
     const int lds = WgTile<T>::BKP * (PY + PX);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN, DMA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN, DMA, DENSE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     WgP q = p;
     q.tiles = ((p.N + 64 * WM - 1) / (64 * WM)) * ((p.Q + 64 * WN - 1) / (64 * WN));
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, DMA>), dim3((unsigned)(q.tiles * splits)), dim3(256), lds, st, q);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, DMA, DENSE>), dim3((unsigned)(q.tiles * splits)), dim3(256), lds, st, q);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
@@ -1912,7 +1928,13 @@ template <typename T, int WM, int WN>
 static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
     static int dma = -1;
     if (dma < 0) { const char* e = getenv("MRFP_WGRAD_DMA"); dma = e ? atoi(e) : 1; }
-    if (sizeof(T) == 2 && dma) return launch_wgrad_v<T, WM, WN, sizeof(T) == 2>(p, splits, st);
+    if (sizeof(T) == 2 && dma) {
+        static int dense = -1;
+        if (dense < 0) { const char* e = getenv("MRFP_WGRAD_DENSE"); dense = e ? atoi(e) : 1; }
+        const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && p.H == p.Ho && p.W == p.Wo;
+        if (dense && pointwise) return launch_wgrad_v<T, WM, WN, sizeof(T) == 2, true>(p, splits, st);
+        return launch_wgrad_v<T, WM, WN, sizeof(T) == 2>(p, splits, st);
+    }
     return launch_wgrad_v<T, WM, WN, false>(p, splits, st);
 }
 

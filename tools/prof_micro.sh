@@ -10,7 +10,7 @@ for mode in "$@"; do
   d=gpurun_out/pm_${shape}_$i
   rm -rf $d
   for kv in $mode; do export $kv; done
-  rocprofv3 --kernel-trace --stats -d $d -o out --output-format csv -- python3 tools/conv_micro.py $shape 30 fwd > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $d -o out --output-format csv -- python3 tools/conv_micro.py $shape 30 ${MICRO_MODE:-fwd} > /dev/null 2>&1
   for kv in $mode; do unset ${kv%%=*}; done
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   echo "== $shape [$mode]"
@@ -19,7 +19,7 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n=r['Name']
-    if 'conv' in n and ('igemm' in n or 'bstat' in n):
+    if "conv" in n or "wgrad" in n:
         print("   %-70s calls %s avg %.1f us"%(n[:70], r['Calls'], float(r['AverageNs'])/1e3))
 PY
 done
