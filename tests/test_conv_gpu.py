@@ -138,16 +138,18 @@ def test_conv_epilogue_statistics_feed_batchnorm(dtype, case):
 
 
 def test_alternative_tile_variants_in_subprocess():
-    """The 256x256 / 8-wave / double-buffered LDS-DMA tile (MRFP_CONV_BIGTILE=1) and the register-staged variants
-    (MRFP_CONV_DMA=0, MRFP_WGRAD_DMA=0) are kept for A/B measurements; the switches are read once per process, so they
-    are exercised in child processes on two of the shapes above."""
+    """Kernel variants kept behind switches for A/B measurements (profiles/r02_experiments.md) -- the 256x256 / 8-wave tile
+    with its ping-pong schedule and asynchronous LDS-DMA ring (MRFP_CONV_BIGTILE=1), the 2-stage asynchronous ring on the
+    4-wave tiles (MRFP_CONV_NBUF=2), the register-staged variants (MRFP_CONV_DMA=0, MRFP_WGRAD_DMA=0), and the generic
+    kernels on the shapes the B-stationary / dense-wgrad kernels normally take (MRFP_CONV_BSTAT=0, MRFP_WGRAD_DENSE=0).  The
+    switches are read once per process, so they are exercised in child processes."""
     import os
     import subprocess
     import sys
     code = (
         "import torch, torch.nn.functional as F\n"
         "from mrfp_amd import conv\n"
-        "for (B,Cin,H,W,Cout,k,pad,dil) in [(2,128,240,240,256,3,1,1),(2,304,120,120,256,3,1,1),(3,64,33,31,64,3,1,1)]:\n"
+        "for (B,Cin,H,W,Cout,k,pad,dil) in [(2,128,240,240,256,3,1,1),(2,304,120,120,256,3,1,1),(3,64,33,31,64,3,1,1),(2,256,48,40,512,1,0,1)]:\n"
         "    g = torch.Generator().manual_seed(1)\n"
         "    x = torch.randn(B,Cin,H,W,generator=g).bfloat16().float(); w = (torch.randn(Cout,Cin,k,k,generator=g)*0.05).bfloat16().float()\n"
         "    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)\n"
@@ -158,7 +160,8 @@ def test_alternative_tile_variants_in_subprocess():
         "    assert rel(yd, yc) < 1e-2 and rel(xd.grad, xc.grad) < 1e-2 and rel(wd.grad, wc.grad) < 2e-2, (Cin, rel(yd,yc), rel(xd.grad,xc.grad), rel(wd.grad,wc.grad))\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"MRFP_CONV_BIGTILE": "1"}, {"MRFP_CONV_DMA": "0", "MRFP_WGRAD_DMA": "0"}, {"MRFP_CONV_DMA": "2"}):
+    for extra in ({"MRFP_CONV_BIGTILE": "1"}, {"MRFP_CONV_DMA": "0", "MRFP_WGRAD_DMA": "0"}, {"MRFP_CONV_NBUF": "2"},
+                  {"MRFP_CONV_BSTAT": "0", "MRFP_WGRAD_DENSE": "0"}):
         env = dict(os.environ, PYTHONPATH=root, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
