@@ -105,16 +105,17 @@ class FlatSGD(FlatArena):
             f = float(group["lr"]) / self.base_lr if self.base_lr > 0 else 1.0
             self.it = int(round(self.max_iter * (1.0 - min(max(f, 0.0), 1.0) ** (1.0 / self.power))))
         state = sd.get("state", {})
-        pos = {idx: j for j, idx in enumerate(group["params"])}     # saved id -> position in model.parameters()
+        # torch numbers the saved parameters 0..P-1 in param_groups[0]["params"] order = model.parameters() order
+        slot = {j: t for t, j in enumerate(self.all_index)}          # position in model.parameters() -> arena slot
         self.flat_m.zero_()
         n = 0
         for key, st in state.items():
-            j = pos.get(key, pos.get(int(key)) if not isinstance(key, int) else None)
-            if j is None or j not in self.all_index or st.get("momentum_buffer") is None:
+            t = slot.get(group["params"].index(int(key)) if int(key) in group["params"] else -1)
+            buf = st.get("momentum_buffer")
+            if t is None or buf is None:
                 continue
-            t = self.all_index.index(j)
             p, o = self.params[t], self.offsets[t]
-            self.flat_m[o:o + p.numel()].copy_(st["momentum_buffer"].reshape(-1).to(self.flat_m.device, torch.float32))
+            self.flat_m[o:o + p.numel()].copy_(buf.reshape(-1).to(self.flat_m.device, torch.float32))
             n += 1
         if 0 < n < len(self.params):
             raise _lib.MrfpHipError("optimizer state covers %d of %d trainable tensors" % (n, len(self.params)))
