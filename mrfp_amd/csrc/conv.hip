@@ -1000,6 +1000,10 @@ static bool use_tile192(const ConvP& p, int esz) {
     return nkt >= 9 && ((p.M + 191) / 192) * ((p.N + 127) / 128) >= 2048;
 }
 
+// (measured and dropped in round 2: a 160x128 tile, 4 waves x 160x32, 71 instead of 55 FLOP per fill byte and 462 tiles
+//  = one round at two workgroups per CU for the M = 36 864, N = 256 layers: 55.9 vs 49.8 us on the 3x3 layer, 31.5 vs
+//  29.3 us on the 1024 -> 256 pointwise layer -- fewer co-resident workgroups cost more than the fill bytes save)
+
 // =============================================================================================
 // B-stationary kernel for the short-K 1x1 convolutions (16-bit types, K = C <= 256, stride 1): Y[M, N] = X[M, K] W[N, K]^T.
 //
@@ -1032,7 +1036,9 @@ struct BsP {
     unsigned xbytes, wbytes, ybytes;
 };
 
-template <typename T, int KB, int NST>
+struct HasPrev { static constexpr bool value = true; };
+struct NoPrev { static constexpr bool value = false; };
+template <typename T, int KB, int NST, bool STATS, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     constexpr int ROWB = KB * 128;              // bytes of one row of X (K elements)
     constexpr int STAGE = KB * 64 * 128;        // one 64-row tile
@@ -1108,83 +1114,131 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     float cs[8], cq[8];                         // per-channel sum / sum of squares over every tile of this workgroup
 #pragma unroll
     for (int u = 0; u < 8; ++u) { cs[u] = 0.f; cq[u] = 0.f; }
-    for (int tile = t0; tile < t1; ++tile) {
-        const int slot = (tile - t0) % NST;
+
+    // SOFTWARE PIPELINE over the tiles: the epilogue of tile t-1 (conversions, statistics, addend, stores: ~150 vector
+    // instructions) is written BETWEEN the k steps of tile t, in one basic block with its multiplies (STATS / ADD are
+    // template parameters, so no branch splits the block): an MFMA holds the SIMD's vector issue for 8 of its 16 cycles, the
+    // other 8 take two ordinary instructions for free, so the epilogue rides in the multiply's issue shadow instead of
+    // running after it with the matrix pipe idle.  Two accumulator sets (A / B) alternate.
+    auto wait_tile = [&](int tile) {
         // younger than the transfer of `tile`: NST-2 transfers and the stores of the NST-1 tiles multiplied since it was issued
         if (tile - t0 >= NST - 1 && tile + NST - 1 <= t1) dma_wait<(NST - 2) * NP + (NST - 1) * ST>();
         else dma_wait<0>();                                               // first / last tiles of the range: fewer behind it
         __builtin_amdgcn_s_barrier();                                     // tile landed everywhere; tile - 1 fully consumed
-        // skip-gradient addend of this tile: fetched NOW (16 registers), consumed after the multiplies -- a load issued in
-        // the epilogue would be waited for right there, once per 16 pixels, with nothing else in this persistent workgroup
-        // to hide it (measured: dgrad launches 58 us against 32 us for the same shape without an addend)
-        const int m0 = tile * 64;
-        // (a compiler-tracked load: its wait in the epilogue also drains the transfers issued below -- they have had the
-        //  whole multiply phase to land.  An untracked inline-asm load with a counted wait was tried and is WRONG: the
-        //  compiler may copy the destination registers before the data has arrived -- the bitwise-reproducibility test
-        //  caught it.)
-        uint4 av[4];
-        if (p.addend) {
+    };
+    auto fetch_addend = [&](int tile, uint4 (&av)[4]) {
+        // skip-gradient addend: fetched before the multiplies of its tile, consumed one tile later (a load issued in the
+        // epilogue would be waited for right there: 58 us against 32 us per dgrad launch).  Compiler-tracked on purpose: an
+        // untracked inline-asm load is WRONG here (the compiler may copy the destination registers before the data has
+        // arrived; the bitwise-reproducibility test caught it).
+        if constexpr (ADD) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i * 16 + l15;
+                const int m = tile * 64 + i * 16 + l15;
                 av[i] = bload(ar, (m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB);
             }
         }
-        if (tile + NST - 1 < t1) issue(tile + NST - 1, (slot + NST - 1) % NST);
-
-        f32x4 acc[4][2];                        // [pixel block of 16][channel block]: rows = channels, columns = pixels
+    };
+    // one quarter (16 pixels) of the epilogue of `tile` from accumulator set acc
+    auto epilogue_part = [&](int tile, int i, const f32x4 (&acc)[4][2], const uint4 (&av)[4]) {
+        const int m = tile * 64 + i * 16 + l15;
+        const bool ok = m < p.M && nl < p.N;                              // (N % 8 == 0 for this kernel: chunks are whole)
+        uint4 v;
+        v.x = pack2<T>(acc[i][0][0], acc[i][0][1]);
+        v.y = pack2<T>(acc[i][0][2], acc[i][0][3]);
+        v.z = pack2<T>(acc[i][1][0], acc[i][1][1]);
+        v.w = pack2<T>(acc[i][1][2], acc[i][1][3]);
+        if constexpr (STATS) {
+            // statistics of the STORED (rounded) values, before the addend.  Rows beyond M were zero-filled by the transfer's
+            // bounds check, so they add exactly 0: no mask.
+            float f[8];
+            unpack2<T>(v.x, f[0], f[1]);
+            unpack2<T>(v.y, f[2], f[3]);
+            unpack2<T>(v.z, f[4], f[5]);
+            unpack2<T>(v.w, f[6], f[7]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-        const char* a = ring + slot * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < KB * 2; ++ks) {
+            for (int u = 0; u < 8; ++u) {
+                cs[u] += f[u];
+                cq[u] += f[u] * f[u];
+            }
+        }
+        if constexpr (ADD) v = chunk_add<T>(v, av[i]);
+        const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
+        u32x4 dv;
+        dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
+        __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)off, 0, 0);
+    };
+    // multiplies of `tile` into acc; when prev >= 0 the epilogue of tile `prev` (accumulators pacc, addend pav) in between
+    auto body = [&](int tile, f32x4 (&acc)[4][2], auto has_prev, const f32x4 (&pacc)[4][2], const uint4 (&pav)[4]) {
+        const int prev = tile - 1;
+        const char* a = ring + ((tile - t0) % NST) * STAGE;
+        constexpr int KS = KB * 2;
+        // fragment reads run ONE K STEP AHEAD of the multiplies that use them (two register sets): left to itself the compiler
+        // issues each pair of reads two MFMAs before their use and waits for them (`s_waitcnt lgkmcnt(1)` after every
+        // second MFMA in the ISA), i.e. an LDS latency per 32 cycles of matrix work
+        uint4 fx[2][4];
+        auto read_x = [&](int ks, uint4 (&f)[4]) {
             const char* ab = a + (ks >> 1) * (64 * 128);
             const int ch = (ks & 1) * 4 + lq;
-            uint4 fx[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fx[i] = *reinterpret_cast<const uint4*>(ab + lds_off(i * 16 + l15, ch));
+            for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const uint4*>(ab + lds_off(i * 16 + l15, ch));
+        };
+        read_x(0, fx[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) read_x(ks + 1, fx[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);    // (the scheduler otherwise sinks the reads back to just before their use)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Mma16<T>::run(acc[i][j], fw[ks][j], fx[i]);
-        }
-
-        // ---- epilogue of this tile, straight from the accumulators: lane = (pixel l15 of block i, channels nl .. nl + 7) ---
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + i * 16 + l15;
-            const bool ok = m < p.M && nl < p.N;                          // (N % 8 == 0 for this kernel: chunks are whole)
-            uint4 v;
-            v.x = pack2<T>(acc[i][0][0], acc[i][0][1]);
-            v.y = pack2<T>(acc[i][0][2], acc[i][0][3]);
-            v.z = pack2<T>(acc[i][1][0], acc[i][1][1]);
-            v.w = pack2<T>(acc[i][1][2], acc[i][1][3]);
-            if (p.colstats) {
-                // statistics of the STORED (rounded) values, before the addend.  Rows beyond M were zero-filled by the
-                // transfer's bounds check, so they add exactly 0: no mask.
-                float f[8];
-                unpack2<T>(v.x, f[0], f[1]);
-                unpack2<T>(v.y, f[2], f[3]);
-                unpack2<T>(v.z, f[4], f[5]);
-                unpack2<T>(v.w, f[6], f[7]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    cs[u] += f[u];
-                    cq[u] += f[u] * f[u];
+                for (int j = 0; j < 2; ++j) {
+                    if (ks == 0) {                // first k step: accumulate onto a literal zero (no register clearing)
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        acc[i][j] = z;
+                    }
+                    Mma16<T>::run(acc[i][j], fw[ks][j], fx[ks & 1][i]);
                 }
+            if constexpr (decltype(has_prev)::value) {
+                // the 4 epilogue quarters of the previous tile, spread over the k steps
+                if constexpr (KS >= 4) { if (ks % (KS / 4) == 0) epilogue_part(prev, ks / (KS / 4), pacc, pav); }
+                else { epilogue_part(prev, 2 * ks, pacc, pav); epilogue_part(prev, 2 * ks + 1, pacc, pav); }
             }
-            if (p.addend) v = chunk_add<T>(v, av[i]);                     // (loaded before the multiplies)
-            const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
-            u32x4 dv;
-            dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
-            __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)off, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    f32x4 accA[4][2], accB[4][2];
+    uint4 avA[4], avB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { avA[i] = make_uint4(0u, 0u, 0u, 0u); avB[i] = make_uint4(0u, 0u, 0u, 0u); }
+    // first tile: multiplies only
+    wait_tile(t0);
+    fetch_addend(t0, avA);
+    if (t0 + NST - 1 < t1) issue(t0 + NST - 1, (NST - 1) % NST);
+    body(t0, accA, NoPrev{}, accB, avB);
+    int tile = t0 + 1;
+    for (; tile + 1 < t1; tile += 2) {
+        wait_tile(tile);
+        fetch_addend(tile, avB);
+        if (tile + NST - 1 < t1) issue(tile + NST - 1, (tile - t0 + NST - 1) % NST);
+        body(tile, accB, HasPrev{}, accA, avA);
+        wait_tile(tile + 1);
+        fetch_addend(tile + 1, avA);
+        if (tile + NST < t1) issue(tile + NST, (tile + 1 - t0 + NST - 1) % NST);
+        body(tile + 1, accA, HasPrev{}, accB, avB);
     }
-    if (p.colstats) {
+    if (tile < t1) {                            // an even number of tiles: one more B step, then its own epilogue
+        wait_tile(tile);
+        fetch_addend(tile, avB);
+        if (tile + NST - 1 < t1) issue(tile + NST - 1, (tile - t0 + NST - 1) % NST);
+        body(tile, accB, HasPrev{}, accA, avA);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue_part(tile, i, accB, avB);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue_part(t1 - 1, i, accA, avA);
+    }
+    if constexpr (STATS) {
         // ONE statistics row block per workgroup range (all its tiles): the 16 lanes of a quarter hold the same 8 channels
         // for 16 different pixels -- fold them (DPP, fixed order) and let lane 0 of the quarter write
         float* out = p.colstats + (size_t)chunk * 2 * p.ldy;
@@ -1210,7 +1264,7 @@ static bool use_bstat(const ConvP& p, int esz, bool has_bias) {
         const char* e = getenv("MRFP_CONV_BSTAT");
         g_bstat = e ? atoi(e) : 1;
     }
-    if (!g_bstat || esz != 2 || has_bias || p.bnx) return false;
+    if (!g_bstat || esz != 2 || has_bias || p.bnx || (p.colstats && p.addend)) return false;
     if (p.R != 1 || p.S != 1 || p.stride != 1 || p.sstride != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
     if (p.Ho != p.H || p.Wo != p.W || p.N < 128 || (p.N & 7) != 0) return false;
     if ((int64_t)p.M * p.ldy * esz >= (int64_t)kOOB) return false;        // the output is addressed through a buffer descriptor
@@ -1230,14 +1284,14 @@ static int bstat_chunks(int M, int N) {
     return (tiles + per - 1) / per;              // ranges that actually hold tiles (the trailing ones would be empty)
 }
 
-template <typename T, int KB>
+template <typename T, int KB, bool STATS, bool ADD>
 static int launch_bstat(const ConvP& c, hipStream_t st) {
     constexpr int NST = KB == 4 ? 2 : 3;                          // K = 256: 2 x 32 KB stages (two workgroups per CU)
     constexpr int STAGE = KB * 64 * 128;
     const int lds = NST * STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bstat_kernel<T, KB, NST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bstat_kernel<T, KB, NST, STATS, ADD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -1254,15 +1308,23 @@ static int launch_bstat(const ConvP& c, hipStream_t st) {
         if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
         if (dbg & 4) p.ybytes = 0;
     }
-    hipLaunchKernelGGL((conv1x1_bstat_kernel<T, KB, NST>), dim3((unsigned)(p.panels * chunks)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv1x1_bstat_kernel<T, KB, NST, STATS, ADD>), dim3((unsigned)(p.panels * chunks)), dim3(256), lds, st, p);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
 
+template <typename T, bool STATS, bool ADD>
+static int run_bstat_v(const ConvP& p, hipStream_t st) {
+    const int kb = p.C * 2 / 128;
+    return kb == 1 ? launch_bstat<T, 1, STATS, ADD>(p, st) : kb == 2 ? launch_bstat<T, 2, STATS, ADD>(p, st) : launch_bstat<T, 4, STATS, ADD>(p, st);
+}
 template <typename T>
 static int run_bstat(const ConvP& p, hipStream_t st) {
-    const int kb = p.C * 2 / 128;
-    return kb == 1 ? launch_bstat<T, 1>(p, st) : kb == 2 ? launch_bstat<T, 2>(p, st) : launch_bstat<T, 4>(p, st);
+    // forward launches carry the fused statistics, dgrad launches the skip-gradient addend; never both in this network
+    if (p.colstats && p.addend) return -1;
+    if (p.colstats) return run_bstat_v<T, true, false>(p, st);
+    if (p.addend) return run_bstat_v<T, false, true>(p, st);
+    return run_bstat_v<T, false, false>(p, st);
 }
 
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
@@ -1512,7 +1574,7 @@ int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64
     p.M = (int)M; p.N = (int)N; p.ldy = (int)N; p.C = (int)C; p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
     // what the kernel choice looks at besides the sizes: `pointwise` = 1x1, stride 1, no padding, output size = input size
     p.R = (int)R; p.S = (int)S; p.stride = pointwise ? 1 : 2; p.sstride = 1; p.pad_h = p.pad_w = 0;
-    p.H = p.W = p.Ho = p.Wo = 1; p.bnx = nullptr; p.bias = nullptr;
+    p.H = p.W = p.Ho = p.Wo = 1; p.bnx = nullptr; p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr;
     return stats_row_blocks(p, esz);
 }
 /* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */
