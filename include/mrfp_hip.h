@@ -334,6 +334,15 @@ int mrfp_u8hwc_to_f32chw(const void* src, float* dst, int64_t H, int64_t W, void
  * 2 saturation, 3 hue (shift = uint8(hue_factor * 255), factor unused).  Byte-exact with PIL. */
 int mrfp_jitter_u8(const void* src, void* dst, int64_t npix, int op, float factor, int shift, void* ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Whitening-loss setup (host-side, no kernel; csrc/hostmath.hip).
+ *   mrfp_kmeans1d: globally optimal k-means of n doubles into k clusters -- what `kmeans1d.cluster(var_flatten,
+ *     self.clusters)` does at reference network/cov_settings.py:57 (kmeans1d is an un-vendored PyPI dependency; its published
+ *     dynamic programme over the sorted values is restated).  labels [n] int32 in input order, clusters numbered by
+ *     ascending centroid; centroids [k] (k is clamped to n).  Host pointers.
+ * ------------------------------------------------------------------------------------------- */
+int mrfp_kmeans1d(const double* x, int64_t n, int k, int32_t* labels, double* centroids);
+
 #ifdef __cplusplus
 }
 #endif

@@ -367,6 +367,10 @@ class MRFPPlus(_DeepLabBase):
         self._tap("layer1", t)
         dec0_fine, low_level = self.bot_fine.forward_skip(t)      # low-level features: decoder + layer2
         t = self._high(low_level, w_arr, fourier)
+        if self.use_wtloss:
+            # the reference stores use_wtloss and never reads it (deepv3.py:167); here it keeps the whitened feature maps of
+            # the last forward so that a training script can add network.cov_settings.whitening_loss(model.w_arr, layers)
+            self.w_arr = w_arr
         self._tap("layer4", t)
         t = self.aspp(t)
         self._tap("aspp", t)

@@ -507,3 +507,89 @@ def fourier_amplitude_mix(x: Tensor, perm: Tensor, radius: float, lam: float = 1
     sel = (~band if high else band)[None, None]
     ratio = torch.where(sel & (A > 1e-20), ((1 - lam) * A + lam * Ap) / A.clamp_min(1e-30), torch.ones_like(A)).detach()
     return torch.fft.irfft2(F_ * ratio, s=(H, W))
+
+
+# --------------------------------------------------------------------------------------
+# Instance-whitening losses (ISW / IRW) -- reference network/instance_whitening.py:19-39 (pinned: tests/golden/
+# whitening.npz holds the reference's own outputs), network/cov_settings.py:8-107 and network/deepv3.py:534-545, 561-567
+# (PARITY UNPINNED for these two: cov_settings.py imports the un-vendored `kmeans1d` and calls .cuda() at construction,
+# so it cannot run in the build container; restated from the source text, the clustering from kmeans1d's published
+# dynamic programme -- here in its plain O(k n^2) form, small inputs only).
+# --------------------------------------------------------------------------------------
+def isw_covariance(f_map: np.ndarray, eps: float = 1e-5) -> np.ndarray:
+    """instance_whitening.py:30-39: [B,C,H,W] -> [B,C,C] = f f^T / (HW - 1) + eps I."""
+    B, C, H, W = f_map.shape
+    f = f_map.reshape(B, C, H * W).astype(np.float64)
+    return np.einsum("bcp,bdp->bcd", f, f) / (H * W - 1) + eps * np.eye(C)
+
+
+def isw_loss(f_map: np.ndarray, mask: np.ndarray, margin: float, num_remove_cov: float) -> float:
+    """instance_whitening.py:19-27."""
+    cor = isw_covariance(f_map) * mask[None]
+    off = np.abs(cor).sum(axis=(1, 2)) - margin
+    return float(np.maximum(off / num_remove_cov, 0.0).sum() / f_map.shape[0])
+
+
+def isw_cov_index_matrix(dim: int) -> np.ndarray:
+    """cov_settings.py:8-14, as the loops it describes."""
+    m = np.zeros((dim, dim), dtype=np.int64)
+    s_index = 0
+    for i in range(dim):
+        for j in range(i + 1, dim):
+            m[i, j] = s_index + j
+        s_index += dim - (2 + i)
+    return m + m.T
+
+
+def kmeans1d_reference(values, k: int):
+    """Optimal 1-D k-means by the textbook dynamic programme (O(k n^2)); labels by ascending centroid."""
+    x = np.asarray(values, dtype=np.float64).reshape(-1)
+    n = x.size
+    k = min(k, n)
+    order = np.argsort(x, kind="stable")
+    xs = x[order]
+    ps = np.concatenate([[0.0], np.cumsum(xs)])
+    ps2 = np.concatenate([[0.0], np.cumsum(xs * xs)])
+
+    def cost(j, i):
+        s, q = ps[i + 1] - ps[j], ps2[i + 1] - ps2[j]
+        return max(q - s * s / (i - j + 1), 0.0)
+    D = np.full((k, n), np.inf)
+    T = np.zeros((k, n), dtype=np.int64)
+    for i in range(n):
+        D[0, i] = cost(0, i)
+    for q in range(1, k):
+        for i in range(q, n):
+            best, bj = np.inf, -1
+            for j in range(q, i + 1):
+                v = D[q - 1, j - 1] + cost(j, i)
+                if v < best:
+                    best, bj = v, j
+            D[q, i], T[q, i] = best, bj
+    labels = np.empty(n, dtype=np.int64)
+    cent = np.empty(k)
+    hi = n - 1
+    for q in range(k - 1, -1, -1):
+        lo = 0 if q == 0 else T[q, hi]
+        labels[order[lo:hi + 1]] = q
+        cent[q] = xs[lo:hi + 1].mean()
+        hi = lo - 1
+    return labels, cent, float(D[k - 1, n - 1])
+
+
+def isw_variance_of_covariance(f_map: np.ndarray) -> np.ndarray:
+    """deepv3.py:536-544: unbiased variance over the batch of the strictly-upper-triangular covariances."""
+    C = f_map.shape[1]
+    off = isw_covariance(f_map) * np.triu(np.ones((C, C)), 1)[None]
+    return off.var(axis=0, ddof=1)
+
+
+def isw_mask(var_matrix: np.ndarray, clusters: int) -> np.ndarray:
+    """cov_settings.py:52-66 with relax_denom == 0: entries outside the lowest k-means cluster, picked as the top-k values."""
+    flat = var_matrix.reshape(-1)
+    labels, _, _ = kmeans1d_reference(flat, clusters)
+    num_sensitive = int(flat.size - (labels == 0).sum())
+    idx = np.argsort(-flat, kind="stable")[:num_sensitive]
+    mask = np.zeros(flat.size)
+    mask[idx] = 1.0
+    return mask.reshape(var_matrix.shape)

@@ -163,3 +163,54 @@ def test_group_isqrt_matches_newton_schulz_autograd():
         out = ops.group_isqrt(cd, T)
         (out * gw).sum().backward()
         assert relerr(out, ref) < 2e-5 and relerr(cd.grad, cr.grad) < 2e-4
+
+
+def test_isw_irw_workflow_on_a_trunk_against_the_restatement():
+    """reference network/deepv3.py:534-545 (cal_covstat), 561-567 (wt_loss) with network/cov_settings.py on the whitened
+    feature maps (w_arr) of a ResNet trunk built with wt_layer codes 2 (ISW) and 1 (IRW): covariance statistics, k-means
+    mask and the loss from the HIP path against oracle/mrfp_oracle.py::isw_* on the same feature maps; the loss's gradient
+    reaches the trunk's first convolution."""
+    from mrfp_amd.config import cfg
+    from mrfp_amd.network import Resnet, cov_settings as cs
+    from oracle import mrfp_oracle as orc
+    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.float32
+    torch.manual_seed(5)
+    net = Resnet.resnet18(pretrained=False, wt_layer=[0, 0, 2, 1, 0, 0, 0]).to(DEV).train()
+    layers, kinds = cs.build_cov_matrix_layers([0, 0, 2, 1, 0, 0, 0], [0, 0, 64, 64, 128, 256, 512], relax_denom=0, clusters=3)
+    assert kinds == [2, 1]
+
+    def w_arr_of(x):
+        from mrfp_amd import ops
+        w_arr = []
+        t = net.conv1(ops.as_activation(x))
+        t = Resnet._norm_relu(net.bn1, net.wt_layer[2], t, w_arr)
+        t = net.layer1([ops.max_pool_3x3_s2(t), w_arr])
+        return t[1]
+    g = torch.Generator().manual_seed(11)
+    acc = None
+    for _ in range(3):                                    # calibration: batches of (image, transformed image)
+        img = torch.rand(1, 3, 64, 64, generator=g)
+        x = torch.cat([img, (img * 1.3 - 0.1).clamp(0, 1)], 0).to(DEV) * 255
+        with torch.no_grad():
+            w_arr = w_arr_of(x)
+        assert len(w_arr) == 2 and w_arr[0].shape[1] == 64
+        cs.covariance_statistics(w_arr[:1], layers[:1])   # only ISW layers keep statistics (CovMatrix_IRW has no such method)
+        v = orc.isw_variance_of_covariance(w_arr[0].float().cpu().numpy())
+        acc = v if acc is None else acc + v
+    assert relerr(layers[0].var_matrix, acc) < 1e-4
+    var_dev = (layers[0].var_matrix / 3).cpu().numpy().astype(np.float64)
+    eye, mask, margin, n_sens = layers[0].get_mask_matrix()
+    np.testing.assert_array_equal(mask.cpu().numpy(), orc.isw_mask(var_dev, 3))
+    assert 0 < float(n_sens) < 64 * 63 / 2
+
+    x = (torch.rand(2, 3, 64, 64, generator=g) * 255).to(DEV)
+    w_arr = w_arr_of(x)
+    loss = cs.whitening_loss(w_arr, layers)
+    ref = 0.0
+    for f, layer in zip(w_arr, layers):
+        e, m, mg, nr = layer.get_mask_matrix()
+        ref += orc.isw_loss(f.detach().float().cpu().numpy(), m.cpu().numpy().astype(np.float64), float(mg), float(nr))
+    assert abs(loss.item() - ref / 2) / (ref / 2) < 1e-4
+    loss.backward()
+    gw = net.conv1.weight.grad
+    assert gw is not None and torch.isfinite(gw).all() and gw.abs().max() > 0
