@@ -269,6 +269,9 @@ template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a,
     return r;
 }
 
+#ifndef MRFP_EARLY
+#define MRFP_EARLY 1
+#endif
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     const bool g_stagger8 = p.stagger8 != 0;
@@ -467,8 +470,48 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
     if constexpr (DMA && NBUF == 1) {
         // single LDS buffer filled by LDS-DMA: no register staging and no ds_write at all; the fill latency of a
         // workgroup is exposed and hidden only by the other workgroups of the CU (more of them fit: fewer registers)
+        if constexpr (M16 && ALIGNED && MRFP_EARLY != 0) {
+            // EARLY ISSUE: the fragments of the LAST k step go to registers, a barrier says "every wave has read the tile",
+            // the transfer of tile kt+1 is issued, and only then the last k step is multiplied -- half of a K tile's matrix
+            // work runs inside the fill latency of the next tile.  (The single buffer bounds the bytes in flight per
+            // workgroup to one tile and only while it is not computing: tools/fill_micro.hip, profiles/r02_experiments.md
+            // section 5 -- the fill path delivers 22-26 TB/s beside an MFMA stream, these kernels draw 13.)  ALIGNED kernels
+            // only: with per-thread tap tracking in the address computation (C = 304) the same reordering costs 29 %.
+            uint4 fa[2 * TM], fb[2 * TN];
+            load_tile(0, ra, rb, 0);
+            for (int kt = 0; kt < nkt; ++kt) {
+                // EXPLICIT vmcnt(0): across the loop's back edge the compiler puts its own wait for the builtin's transfers AFTER
+                // the barrier (`s_waitcnt vmcnt(5); s_barrier; s_waitcnt vmcnt(0); ds_read` in the ISA) -- a wave would pass the
+                // barrier with its pieces still in flight and the others would read stale LDS (caught by the bitwise
+                // reproducibility test of the full-size model, not by the small convolution cases)
+                dma_wait<0>();
+                __syncthreads();      // barrier: tile kt has landed everywhere
+                compute(0, 0, 1);
+                {
+                    const int ch = 4 + lq;
+#pragma unroll
+                    for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA0 + lds_off(wm * 32 * TM + i * 16 + l15, ch));
+#pragma unroll
+                    for (int j = 0; j < 2 * TN; ++j) {
+                        const int brow = TR ? 32 * (j >> 1) + 8 * (l15 >> 2) + 4 * (j & 1) + (l15 & 3) : j * 16 + l15;
+                        fb[j] = *reinterpret_cast<const uint4*>(sB0 + lds_off(wn * 32 * TN + brow, ch));
+                    }
+                }
+                __syncthreads();      // lgkmcnt(0) + barrier: every wave holds its last fragments, the buffer is free
+                if (kt + 1 < nkt) load_tile(kt + 1, ra, rb, 0);
+#pragma unroll
+                for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2 * TN; ++j) {
+                        if constexpr (TR) Mma16<T>::run(acc16[i][j], fb[j], fa[i]);
+                        else Mma16<T>::run(acc16[i][j], fa[i], fb[j]);
+                    }
+            }
+            __syncthreads();          // the epilogue reuses the buffer
+        } else
         for (int kt = 0; kt < nkt; ++kt) {
             load_tile(kt, ra, rb, 0);
+            dma_wait<0>();            // (the compiler's own wait sits here as well; spelled out so that it cannot move behind the barrier)
             __syncthreads();          // vmcnt(0) + barrier: the tile has landed
             compute(0);
             __syncthreads();          // everybody is done reading before the next fill
@@ -1121,8 +1164,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     // other 8 take two ordinary instructions for free, so the epilogue rides in the multiply's issue shadow instead of
     // running after it with the matrix pipe idle.  Two accumulator sets (A / B) alternate.
     auto wait_tile = [&](int tile) {
-        // younger than the transfer of `tile`: NST-2 transfers and the stores of the NST-1 tiles multiplied since it was issued
-        if (tile - t0 >= NST - 1 && tile + NST - 1 <= t1) dma_wait<(NST - 2) * NP + (NST - 1) * ST>();
+        // younger than the transfer of `tile` (issued in iteration tile-NST+1, before that iteration's body): the NST-2
+        // transfers of the tiles behind it and the stores issued in the bodies of iterations tile-NST+1 .. tile-1 -- which,
+        // one tile late in this pipeline, are those of tiles tile-NST .. tile-2: NST-1 batches, all of them real only from
+        // tile t0+NST on (the body of t0 has no epilogue in it; counting its absent stores let the second tile of a range be
+        // read before its last pieces had landed)
+        if (tile - t0 >= NST && tile + NST - 1 <= t1) dma_wait<(NST - 2) * NP + (NST - 1) * ST>();
         else dma_wait<0>();                                               // first / last tiles of the range: fewer behind it
         __builtin_amdgcn_s_barrier();                                     // tile landed everywhere; tile - 1 fully consumed
     };
