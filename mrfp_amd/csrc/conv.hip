@@ -1788,6 +1788,9 @@ template <> struct WgFrag<float> {
     static constexpr int KSTEP = 8;
 };
 
+#ifndef MRFP_WGRAD_HOLD
+#define MRFP_WGRAD_HOLD 2      // k steps (of 4 per K' tile) multiplied after the next tile's transfer has been issued
+#endif
 template <typename T> struct WgTile { static constexpr int BKP = 64; };   // pixels per K' tile
 template <> struct WgTile<float> { static constexpr int BKP = 32; };
 
@@ -1925,11 +1928,16 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
     uint4 ry[SY], rx[SX];
     if (DMA) {
         // single LDS buffer filled by LDS-DMA (as the forward kernel, mode 3): no staging registers, no ds_write
+        // EARLY ISSUE (as in conv_igemm_kernel): the fragments of the last HOLD k steps go to registers, a barrier frees the
+        // buffer, the next tile's transfer is issued and the held k steps are multiplied inside its latency.
+        constexpr int KSN = BKP / 16;
+        constexpr int HOLD = (!DENSE && WM == 1) ? 1 : MRFP_WGRAD_HOLD;     // (the 64x256 gather variant spills with two held k steps)
+        if (nkt > 0) load_tile(kbeg, ry, rx);
         for (int kt = 0; kt < nkt; ++kt) {
-            load_tile(kbeg + kt * BKP, ry, rx);
-            __syncthreads();          // vmcnt(0) + barrier: the tile has landed
+            dma_wait<0>();            // explicit: across the back edge the compiler's own wait lands behind the barrier
+            __syncthreads();          // the tile has landed everywhere
 #pragma unroll
-            for (int ks = 0; ks < BKP / 16; ++ks) {
+            for (int ks = 0; ks < KSN - HOLD; ++ks) {
                 uint4 fa[2], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[i] = wg_read_sw<NBY>(ty, wm * 64 + i * 32, ks * 16, lane);
@@ -1940,7 +1948,22 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
             }
-            __syncthreads();          // everybody is done reading before the next fill
+            uint4 ha[HOLD > 0 ? HOLD : 1][2], hb[HOLD > 0 ? HOLD : 1][2];
+#pragma unroll
+            for (int h = 0; h < HOLD; ++h) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ha[h][i] = wg_read_sw<NBY>(ty, wm * 64 + i * 32, (KSN - HOLD + h) * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) hb[h][j] = wg_read_sw<NBX>(tx, wn * 64 + j * 32, (KSN - HOLD + h) * 16, lane);
+            }
+            __syncthreads();          // lgkmcnt(0) + barrier: everybody is done reading, the buffer is free
+            if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BKP, ry, rx);
+#pragma unroll
+            for (int h = 0; h < HOLD; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], ha[h][i], hb[h][j]);
         }
     } else {
     if (nkt > 0) {
