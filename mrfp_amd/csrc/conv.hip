@@ -272,6 +272,9 @@ template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a,
 #ifndef MRFP_EARLY
 #define MRFP_EARLY 1
 #endif
+#ifndef MRFP_EARLY_FULL
+#define MRFP_EARLY_FULL 1
+#endif
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     const bool g_stagger8 = p.stagger8 != 0;
@@ -477,35 +480,40 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
             // workgroup to one tile and only while it is not computing: tools/fill_micro.hip, profiles/r02_experiments.md
             // section 5 -- the fill path delivers 22-26 TB/s beside an MFMA stream, these kernels draw 13.)  ALIGNED kernels
             // only: with per-thread tap tracking in the address computation (C = 304) the same reordering costs 29 %.
-            uint4 fa[2 * TM], fb[2 * TN];
+            // HOLD = 2 (both k steps of the K tile held: the whole multiply runs inside the next fill) where the register budget
+            // of the tile's occupancy allows it (MRFP_EARLY_FULL, bit 0: 96x128 tile, bit 1: 128x128 tile)
+            constexpr int HOLD = ((TM * TN == 3 && (MRFP_EARLY_FULL & 1)) || (TM * TN == 4 && WM == 2 && WN == 2 && (MRFP_EARLY_FULL & 2))) ? 2 : 1;
+            uint4 fa[HOLD][2 * TM], fb[HOLD][2 * TN];
             load_tile(0, ra, rb, 0);
             for (int kt = 0; kt < nkt; ++kt) {
                 // EXPLICIT vmcnt(0): across the loop's back edge the compiler puts its own wait for the builtin's transfers AFTER
                 // the barrier (`s_waitcnt vmcnt(5); s_barrier; s_waitcnt vmcnt(0); ds_read` in the ISA) -- a wave would pass the
-                // barrier with its pieces still in flight and the others would read stale LDS (caught by the bitwise
-                // reproducibility test of the full-size model, not by the small convolution cases)
+                // barrier with its pieces still in flight and the others would read stale LDS
                 dma_wait<0>();
                 __syncthreads();      // barrier: tile kt has landed everywhere
-                compute(0, 0, 1);
-                {
-                    const int ch = 4 + lq;
+                if constexpr (HOLD == 1) compute(0, 0, 1);
 #pragma unroll
-                    for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA0 + lds_off(wm * 32 * TM + i * 16 + l15, ch));
+                for (int h = 0; h < HOLD; ++h) {
+                    const int ch = (2 - HOLD + h) * 4 + lq;
+#pragma unroll
+                    for (int i = 0; i < 2 * TM; ++i) fa[h][i] = *reinterpret_cast<const uint4*>(sA0 + lds_off(wm * 32 * TM + i * 16 + l15, ch));
 #pragma unroll
                     for (int j = 0; j < 2 * TN; ++j) {
                         const int brow = TR ? 32 * (j >> 1) + 8 * (l15 >> 2) + 4 * (j & 1) + (l15 & 3) : j * 16 + l15;
-                        fb[j] = *reinterpret_cast<const uint4*>(sB0 + lds_off(wn * 32 * TN + brow, ch));
+                        fb[h][j] = *reinterpret_cast<const uint4*>(sB0 + lds_off(wn * 32 * TN + brow, ch));
                     }
                 }
                 __syncthreads();      // lgkmcnt(0) + barrier: every wave holds its last fragments, the buffer is free
                 if (kt + 1 < nkt) load_tile(kt + 1, ra, rb, 0);
 #pragma unroll
-                for (int i = 0; i < 2 * TM; ++i)
+                for (int h = 0; h < HOLD; ++h)
 #pragma unroll
-                    for (int j = 0; j < 2 * TN; ++j) {
-                        if constexpr (TR) Mma16<T>::run(acc16[i][j], fb[j], fa[i]);
-                        else Mma16<T>::run(acc16[i][j], fa[i], fb[j]);
-                    }
+                    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2 * TN; ++j) {
+                            if constexpr (TR) Mma16<T>::run(acc16[i][j], fb[h][j], fa[h][i]);
+                            else Mma16<T>::run(acc16[i][j], fa[h][i], fb[h][j]);
+                        }
             }
             __syncthreads();          // the epilogue reuses the buffer
         } else
