@@ -969,7 +969,7 @@ static int launch_igemm(const ConvP& p, hipStream_t st) {
     // workgroups of a CU hide each other's fill latency), the 8-wave tile runs the asynchronous ring.
     // MRFP_CONV_NBUF=2: every tile runs a 2-stage ring filled by asynchronous LDS-DMA (conv_igemm_kernel).  Measured in
     // round 2 (tools/ab_nbuf.sh, profiles/r02_experiments.md): -5 % on every shape (3 stages: -25 %) -- a second stage
-    // costs a co-resident workgroup, and the fill path (L2 -> LDS, ~14 TB/s) is throughput-bound, not latency-bound.
+    // costs a co-resident workgroup for the same bytes in flight (every byte in flight needs LDS to land in: tools/fill_micro.hip).
     static int dma = -1, nbuf = -1;
     if (dma < 0) {
         const char* e = getenv("MRFP_CONV_DMA");

@@ -65,6 +65,60 @@ __global__ __launch_bounds__(256) void fill_kernel(const char* src, unsigned lon
     if (s == 123.456f) sink[0] = s;
 }
 
+// the convolution kernels' A-tile pattern: one DMA instruction = 8 rows x 128 B (lane -> row lane>>3, 16-byte chunk lane&7), the rows
+// `stride` bytes apart (a pixel's channel vector), a tile = 192 consecutive rows, the K loop walks `ksteps` 128-byte columns of the
+// same rows and then moves to the next 192 rows; all inside a 2 MiB window per 16 workgroups (L2 hits)
+__global__ __launch_bounds__(256) void gather_kernel(const char* src, unsigned stride, int ksteps, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned rows_per_window = (2u << 20) / stride;            // rows in a 2 MiB window
+    const char* p = src + (unsigned long long)(blockIdx.x & 15) * (2ull << 20);
+    i32x4 r;
+    r.x = (int)(unsigned)(unsigned long long)p;
+    r.y = (int)(((unsigned long long)p >> 32) & 0xffffu);
+    r.z = (int)0x7fffffff;
+    r.w = 0x00020000;
+    unsigned row0 = ((unsigned)(blockIdx.x >> 4) * 192u) % rows_per_window;
+    int kt = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                                 // 192 rows = 24 pieces of 8 rows, 6 per wave
+            unsigned row = row0 + (unsigned)((q * 4 + wave) * 8 + (lane >> 3));
+            if (row >= rows_per_window) row -= rows_per_window;
+            const unsigned o = row * stride + (unsigned)kt * 128u + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+            dma16(r, lds0 + (unsigned)(((it & 1) * 24 + q * 4 + wave) * 1024), o);
+        }
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (++kt == ksteps) {
+            kt = 0;
+            row0 += 192u * 97u;                                       // another tile of the window
+            row0 %= rows_per_window;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((float)smem[(t * 16) & 16383] == 123.456f) sink[0] = 1.f;
+}
+
+static void run_gather(const char* d, unsigned stride, int wpc, int iters, float* sink) {
+    const int grid = 256 * wpc, ksteps = (int)(stride / 128u);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 49152, 0, d, stride, ksteps, iters / 8, sink);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 49152, 0, d, stride, ksteps, iters, sink);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)grid * iters * 24576.0;
+    printf("gather 8 rows x 128 B, row stride %5u B, %d WG/CU: %7.2f TB/s chip  %6.1f GB/s per CU  (%.3f ms)\n", stride, wpc,
+           bytes / ms * 1e-9, bytes / ms * 1e-6 / 256.0, ms);
+}
+
 template <int MODE>
 static void run(const char* name, const char* d, unsigned long long span, int wpc, int iters, float* sink) {
     const int grid = 256 * wpc;
@@ -98,5 +152,8 @@ int main() {
             run<1>("register loads", d, span, wpc, iters, sink);
             run<2>("LDS-DMA + 16 MFMA per tile", d, span, wpc, iters, sink);
         }
+    const unsigned strides[] = {128u, 256u, 512u, 640u, 1024u, 1152u, 2048u, 2176u, 4096u, 4224u};
+    for (int wpc = 2; wpc <= 3; ++wpc)
+        for (unsigned st : strides) run_gather(d, st, wpc, 2048, sink);
     return 0;
 }
