@@ -219,9 +219,12 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
  * float [nblk][2][ldy] (sum, sum of squares per row block), nblk = mrfp_conv_stats_blocks(...): the
  * BatchNorm statistics pass over the conv output disappears (feed it to mrfp_bn_finalize with B = 1,
  * nslab = nblk, count = B*Ho*Wo). */
-int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S, int64_t pointwise);
-/* pointwise = 1 for a 1x1 convolution with stride 1, no padding and output size = input size (the launch then may run on
- * the B-stationary kernel, whose row blocks are 64 rows), else 0. */
+int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho,
+                               int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, int64_t bn_bwd);
+/* takes the geometry arguments of the mrfp_conv_fwd call it describes (bn_bwd = 0), or of the convolution a
+ * mrfp_conv_dgrad_bnstats call (bn_bwd = 1, stride = 1, that call's own B, H, W, C, N, ...; see below): the kernel the launch
+ * runs on (tile shape, the B-stationary pointwise kernel, the row-reuse 3x3 kernels) -- and with it the number of row blocks --
+ * depends on all of them. */
 /* The K-loop gathers through 32-bit buffer-descriptor offsets, so one launch reads at most 3.75 GB of input; a larger
  * activation (BASELINE.json configs[4] at 16 images per GPU: 16 x 256 x 512 x 1024 bf16 = 4.3 GB) is walked in batch ranges
  * by mrfp_conv_fwd / mrfp_conv_wgrad themselves (one image must stay below the limit).  Returns 1 when B images of
@@ -239,7 +242,7 @@ int64_t mrfp_conv_stats_final_count(int64_t nblk);
  *   mask = (bn_y > 0) if bn_y != NULL, else (bn_x*bn_fA[n] + bn_fS[n] > 0) if bn_fA != NULL, else 1
  * (bn_x / bn_y: the BatchNorm's input / output, [B,Ho,Wo,N] dense, same dtype) -- the layout mrfp_stats_bwd produces, so the
  * separate pass over (dy, x) disappears: hand rows [final_first, final_first + final_count) of bnstats (float
- * [mrfp_conv_stats_rows(nblk)][2][N], nblk = mrfp_conv_stats_blocks(dtype, B*Ho*Wo, N, C, R, S, 0)) to mrfp_bn_bwd_finalize
+ * [mrfp_conv_stats_rows(nblk)][2][N], nblk = mrfp_conv_stats_blocks(dtype, B, H, W, C, N, R, S, Ho, Wo, 1, pad_h, pad_w, dil, sstride, 1) with this call's own arguments) to mrfp_bn_bwd_finalize
  * with B = 1, nslab = final_count.  Needs mrfp_conv_dgrad_bnstats_ok(dtype, C, N) (C*sizeof % 128 == 0, N*sizeof % 16 == 0). */
 int mrfp_conv_dgrad_bnstats_ok(int dtype, int64_t C, int64_t N);
 int mrfp_conv_dgrad_bnstats(const void* dy, const void* wpack, void* dx, int dtype, int64_t B, int64_t H, int64_t W,

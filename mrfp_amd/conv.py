@@ -184,8 +184,7 @@ class _Conv2d(torch.autograd.Function):
         L = _lib.lib()
         if bias is None and FUSE_STATS[0] and L.mrfp_conv_single_launch(B, H * W * Cphys * x.element_size()):
             # no bias = a convolution that feeds a normalisation layer: let the epilogue produce its statistics
-            pointwise = int(R == 1 and S == 1 and stride == 1 and pad_h == 0 and pad_w == 0 and Ho == H and Wo == W)
-            nblk = int(L.mrfp_conv_stats_blocks(dt(x), B * Ho * Wo, Nphys, Cphys, R, S, pointwise))
+            nblk = int(L.mrfp_conv_stats_blocks(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1, 0))
             stats = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Nphys, dtype=torch.float32, device=x.device)
         call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
              Ho, Wo, stride, pad_h, pad_w, dil, 1, None, ptr(stats), stream())
@@ -229,7 +228,8 @@ class _Conv2d(torch.autograd.Function):
                     L.mrfp_conv_dgrad_bnstats_ok(dt(dy), Nphys, Cphys) and \
                     L.mrfp_conv_single_launch(B, Ho * Wo * Nphys * dy.element_size()):
                 # dx is dL/d(BatchNorm output): its backward statistics come out of this launch's epilogue
-                nblk = int(L.mrfp_conv_stats_blocks(dt(dy), B * H * W, Cphys, Nphys, R, S, 0))    # (bnx launches never run pointwise)
+                nblk = int(L.mrfp_conv_stats_blocks(dt(dy), B, Ho, Wo, Nphys, Cphys, R, S, H, W, 1, dil * (R - 1) - pad_h,
+                                                     dil * (S - 1) - pad_w, dil, stride, 1))
                 st = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Cphys, dtype=torch.float32, device=x.device)
                 call("mrfp_conv_dgrad_bnstats", ptr(dy), ptr(pk.wd), ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, R, S, H, W,
                      dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), ptr(bn["x"]),

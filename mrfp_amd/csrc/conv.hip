@@ -272,11 +272,14 @@ template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a,
 #ifndef MRFP_EARLY
 #define MRFP_EARLY 1
 #endif
+#ifndef MRFP_RR_HOLD
+#define MRFP_RR_HOLD 1         // k steps (of the 6 per filter row) of the row-reuse kernels multiplied after the next fill has been issued
+#endif
 #ifndef MRFP_EARLY_FULL
 #define MRFP_EARLY_FULL 1
 #endif
-template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false>
-__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
+template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false, bool RR = false>
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || RR ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     const bool g_stagger8 = p.stagger8 != 0;
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
@@ -470,7 +473,104 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 ? 2 : 3)) void conv_ige
                 for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
     };
-    if constexpr (DMA && NBUF == 1) {
+    if constexpr (RR) {
+        // ---- ROW REUSE (3x3, stride 1, pad = dil): the three taps of one filter row read the SAME input pixels shifted by one
+        // (dil) column, so ONE fill of a haloed pixel patch serves all three -- the A bytes through the fill path drop to a
+        // third (+ halo) and the tile's FLOP per fill byte goes from 77 to 128 (192x128) without a larger register tile
+        // (profiles/r02_experiments.md section 5: these kernels are bound by the bytes they pull through that path).
+        // The M tile is PW = min(W, BM) consecutive pixels of RT = BM / PW image rows (host: W % 16 == 0, H*W % BM == 0, so
+        // a 16-pixel fragment block never straddles an image row and a tile never straddles an image).  LDS patch: RT row
+        // segments of PW + 2*dil pixels, 128 B (64 channels) each; tap s of pixel x reads patch column x + s*dil.  K order:
+        // 64-channel chunk (outer), filter row r, tap s (inner): A is filled per (chunk, r), B (one tap's 128 x 64 weights) per
+        // tap, each transfer issued as early as the single buffers allow (see the early-issue loop below).
+        static_assert(M16 && ALIGNED && !STRIDED && DMA && NBUF == 1 && !BNB, "row-reuse kernels");
+        constexpr int ARR = BM + 32, SAR = ARR / RSTEP;       // LDS rows of the patch (whole DMA pieces), pieces per wave
+        char* const sBr = smem + ARR * 128;       // three weight tiles of BN x 64 channels
+        const int dil = p.dil;
+        const int PW = p.W < BM ? p.W : BM, RT = BM / PW, PWH = PW + 2 * dil;
+        const int hw = p.H * p.W;
+        const int b0 = m0 / hw, rem0 = m0 - b0 * hw, oh0 = rem0 / p.W, ow0 = rem0 - oh0 * p.W;
+        unsigned r_j = 0, r_okm = 0;   // per piece i: image row j of its patch row (4 bits each) and "inside the image row" bit
+        unsigned r_base[SAR];   // byte offset of its pixel at filter row r = 1 (the centre row), chunk included
+#pragma unroll
+        for (int i = 0; i < SAR; ++i) {
+            const int L = rbase + i * RSTEP;
+            const int j = L / PWH, x = L - j * PWH - dil, col = ow0 + x;
+            const bool ok = j < RT && col >= 0 && col < p.W;
+            r_j |= (unsigned)(j & 15) << (4 * i);
+            r_okm |= (ok ? 1u : 0u) << i;
+            r_base[i] = (unsigned)((b0 * p.H + oh0 + j) * p.W + col) * (unsigned)pixbytes + (unsigned)(chunk * 16);
+        }
+        auto fill_a = [&](int cc, int r) {
+            const int dh = (r - 1) * dil;
+            const unsigned add = (unsigned)(dh * p.W * pixbytes + cc * 128);
+#pragma unroll
+            for (int i = 0; i < SAR; ++i) {
+                const int ih = oh0 + (int)((r_j >> (4 * i)) & 15u) + dh;
+                const bool ok = ((r_okm >> i) & 1u) && (unsigned)ih < (unsigned)p.H;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(sA0 + (wrow + i * RSTEP) * 128), 16,
+                                                         (int)(ok ? r_base[i] + add : kOOB), 0, 0, 0);
+            }
+        };
+        // the weights of the three taps of filter row r: three 128 x 64 tiles side by side
+        auto fill_b3 = [&](int cc, int r) {
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const unsigned qoff = (unsigned)((r * 3 + s_) * p.cpr + cc * 8 + chunk) * 16u;
+#pragma unroll
+                for (int i = 0; i < SB; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sBr + s_ * (BN * 128) + (wrow + i * RSTEP) * 128), 16,
+                                                             (int)(b_base[i] >= kOOB ? kOOB : b_base[i] + qoff), 0, 0, 0);
+            }
+        };
+        int arow[2 * TM];       // patch row of the first pixel of fragment block i, tap 0 (wave-uniform: scalar registers)
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) {
+            const int pb = __builtin_amdgcn_readfirstlane(wm) * 32 * TM + i * 16;
+            const int j = pb / PW;
+            arow[i] = __builtin_amdgcn_readfirstlane(j * PWH + (pb - j * PW));
+        }
+        auto read_frags = [&](int kk, int s_, uint4 (&fa)[2 * TM], uint4 (&fb)[2 * TN]) {
+            const int ch = kk * 4 + lq;
+            const int sh = s_ * dil + l15;
+            const char* bt = sBr + s_ * (BN * 128);
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA0 + lds_off(arow[i] + sh, ch));
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(bt + lds_off(wn * 32 * TN + j * 16 + l15, ch));
+        };
+        auto mma_frags = [&](const uint4 (&fa)[2 * TM], const uint4 (&fb)[2 * TN]) {
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2 * TN; ++j) Mma16<T>::run(acc16[i][j], fa[i], fb[j]);
+        };
+        const int ncc = p.cpr >> 3;
+        fill_a(0, 0);
+        fill_b3(0, 0);
+        for (int cc = 0; cc < ncc; ++cc)
+            for (int r = 0; r < 3; ++r) {
+                uint4 fa[2 * TM], fb[2 * TN], ga[2 * TM], gb[2 * TN];
+                dma_wait<0>();                // (explicit: see the early-issue loop below)
+                __syncthreads();              // the patch and the three weight tiles have landed
+#pragma unroll
+                for (int it = 0; it < 6 - MRFP_RR_HOLD; ++it) {      // (tap, k step) = (0,0) (0,1) (1,0) (1,1) [(2,0)]: no barrier in between
+                    read_frags(it & 1, it >> 1, fa, fb);
+                    mma_frags(fa, fb);
+                }
+                if constexpr (MRFP_RR_HOLD == 2) read_frags(0, 2, ga, gb);
+                read_frags(1, 2, fa, fb);
+                __syncthreads();              // every wave holds its last fragments: the buffers are free
+                const int rn = r == 2 ? 0 : r + 1, cn = r == 2 ? cc + 1 : cc;
+                if (cn < ncc) {
+                    fill_a(cn, rn);
+                    fill_b3(cn, rn);
+                }
+                if constexpr (MRFP_RR_HOLD == 2) mma_frags(ga, gb);
+                mma_frags(fa, fb);
+            }
+        __syncthreads();                      // the epilogue reuses the buffers
+    } else if constexpr (DMA && NBUF == 1) {
         // single LDS buffer filled by LDS-DMA: no register staging and no ds_write at all; the fill latency of a
         // workgroup is exposed and hidden only by the other workgroups of the CU (more of them fit: fewer registers)
         if constexpr (M16 && ALIGNED && MRFP_EARLY != 0) {
@@ -990,6 +1090,26 @@ static int launch_igemm(const ConvP& p, hipStream_t st) {
     return launch_igemm_nb<T, WM, WN, ALIGNED, STRIDED, 1, TM, TN, true>(p, st);
 }
 
+// row-reuse kernels (conv_igemm_kernel<..., RR = true>): 3x3, stride 1, pad = dil, 64-channel-aligned C, W % 16 == 0
+template <typename T, int WM, int WN, int TM, int TN>
+static int launch_igemm_rr(const ConvP& p, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int EP = WM * WN * 32 * (32 * TN * (int)sizeof(T) + 16);
+    const int fill = (BM + 32 + 3 * BN) * 128;
+    const int lds = fill > EP ? fill : EP;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN, true, false, 1, TM, TN, true, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, true, false, 1, TM, TN, true, false, true>), dim3((unsigned)tiles),
+                       dim3(64 * WM * WN), lds, st, p);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T, int WM, int WN, int TM, int TN>
 static int pick_igemm(const ConvP& p, hipStream_t st) {
     const bool aligned = (p.cpr & 7) == 0, strided = p.sstride > 1;
@@ -1054,6 +1174,29 @@ static bool use_tile192(const ConvP& p, int esz) {
 // (measured and dropped in round 2: a 160x128 tile, 4 waves x 160x32, 71 instead of 55 FLOP per fill byte and 462 tiles
 //  = one round at two workgroups per CU for the M = 36 864, N = 256 layers: 55.9 vs 49.8 us on the 3x3 layer, 31.5 vs
 //  29.3 us on the 1024 -> 256 pointwise layer -- fewer co-resident workgroups cost more than the fill bytes save)
+
+// Row-reuse kernels: the tile (192 or 96 rows; 0 = not applicable) a launch runs on.  MRFP_CONV_RR=0: off; 1: where the plain
+// kernel would run the same tile shape; 2: also instead of the 128x128 tile where a row-reuse tile fits.
+static int g_rr = -1;
+static int rr_tile(const ConvP& p, int esz) {
+    if (g_rr < 0) {
+        const char* e = getenv("MRFP_CONV_RR");
+        g_rr = e ? atoi(e) : 2;
+    }
+    if (!g_rr || esz != 2 || p.N <= 64 || p.bnx || use_big_tile(p, esz)) return 0;
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.sstride != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
+    if (p.dil < 1 || p.dil > 2 || p.pad_h != p.dil || p.pad_w != p.dil) return 0;
+    if ((p.cpr & 7) != 0 || (p.W & 15) != 0) return 0;
+    auto fits = [&](int BM) {
+        if ((p.H * p.W) % BM != 0 || (p.W % BM != 0 && BM % p.W != 0)) return false;
+        const int PW = p.W < BM ? p.W : BM, RT = BM / PW;
+        return RT * (PW + 2 * p.dil) <= BM + 32;
+    };
+    if (use_tile192(p, esz)) return fits(192) ? 192 : 0;
+    if (g_rr >= 2 && fits(192)) return 192;
+    if (g_rr >= 3 && fits(96)) return 96;
+    return 0;
+}
 
 // =============================================================================================
 // B-stationary kernel for the short-K 1x1 convolutions (16-bit types, K = C <= 256, stride 1): Y[M, N] = X[M, K] W[N, K]^T.
@@ -1385,6 +1528,7 @@ static int run_bstat(const ConvP& p, hipStream_t st) {
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
 static int64_t stats_row_blocks(const ConvP& p, int esz) {
     if (use_bstat(p, esz, false)) return (int64_t)bstat_chunks(p.M, p.N);               // conv1x1_bstat_kernel: one per workgroup range
+    if (const int rr = rr_tile(p, esz)) return rr == 192 ? (int64_t)(p.M / 192) * 2 : (int64_t)(p.M / 96);   // row-reuse variants of the two tiles below
     if (p.N > 64 && use_tile192(p, esz)) return (int64_t)((p.M + 191) / 192) * 2;      // <2,2,3,2>: 192-row tile, 2 wave rows
     if (p.N <= 64) return (int64_t)((p.M + 255) / 256) * 4;          // <4,1,2,2>: 256-row tile, 4 wave rows
     if (use_big_tile(p, esz)) return (int64_t)((p.M + 255) / 256) * 2;  // <2,4,4,2>: 256-row tile, 2 wave rows
@@ -1398,6 +1542,9 @@ static int run_igemm(const ConvP& p, hipStream_t st) {
         if (use_bstat(p, 2, p.bias != nullptr)) return run_bstat<T>(p, st);
     }
     if (p.N <= 64) return pick_igemm<T, 4, 1, 2, 2>(p, st);
+    if constexpr (sizeof(T) == 2) {
+        if (const int rr = rr_tile(p, 2)) return rr == 192 ? launch_igemm_rr<T, 2, 2, 3, 2>(p, st) : launch_igemm_rr<T, 1, 4, 3, 1>(p, st);
+    }
     // 256x256 tile (8 waves x 128x64, LDS-DMA, one workgroup per CU).  Measured per shape on MI355X inside the
     // bench workload (bench.py --dump-convs): +8..10 % on long-K 3x3 layers with >= 2 full rounds of tiles
     // (998 vs 913 TF/s at 16x192x192x256->256), but -25 % with ~1 round (M = 36 864), -20 % on short-K 1x1
@@ -1623,13 +1770,18 @@ int mrfp_conv_dgrad_bnstats(const void* dy, const void* wpack, void* dx, int dty
                          bnstats, bn_x, bn_y, bn_mean, bn_fA, bn_fS, stream);
 }
 
-int64_t mrfp_conv_stats_blocks(int dtype, int64_t M, int64_t N, int64_t C, int64_t R, int64_t S, int64_t pointwise) {
+int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho,
+                               int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, int64_t bn_bwd) {
+    // the SAME geometry the launch will see (conv_fwd_impl): the kernel choice -- and with it the number of row blocks -- looks at
+    // the filter, stride, padding, dilation and image size, not only at M, N, C
     ConvP p;
     const int esz = dtype == MRFP_F32 ? 4 : 2;
-    p.M = (int)M; p.N = (int)N; p.ldy = (int)N; p.C = (int)C; p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
-    // what the kernel choice looks at besides the sizes: `pointwise` = 1x1, stride 1, no padding, output size = input size
-    p.R = (int)R; p.S = (int)S; p.stride = pointwise ? 1 : 2; p.sstride = 1; p.pad_h = p.pad_w = 0;
-    p.H = p.W = p.Ho = p.Wo = 1; p.bnx = nullptr; p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr;
+    p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)N;
+    p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
+    p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
+    p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    p.bnx = bn_bwd ? "" : nullptr;      // (only tested against null by the kernel choice)
+    p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr;
     return stats_row_blocks(p, esz);
 }
 /* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */

@@ -229,3 +229,36 @@ def test_repeated_launches_are_bit_identical(shape):
     for y, s in zip(ys[1:], sts[1:]):
         assert torch.equal(ys[0], y) and torch.equal(sts[0], s)
     assert ((ys[0].float() - ref).abs().max() / ref.abs().max()).item() < 1.5e-2
+
+
+def test_row_reuse_kernels_in_subprocess():
+    """conv_igemm_kernel<..., RR = true> (3x3, stride 1, pad = dilation: one fill of a haloed pixel patch serves the three taps of
+    a filter row) on every tile geometry it supports -- a tile inside one image row (W = 384, 192), whole rows per tile (W = 96,
+    48, 16), dilation 2, batch > 1 -- forward + dgrad (the same kernel on the flipped pack) against torch, and repeated
+    launches bit-identical.  MRFP_CONV_RR=2 routes every eligible shape to these kernels (read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, torch.nn.functional as F\n"
+        "from mrfp_amd import conv\n"
+        "for (B,Cin,H,W,Cout,pad) in [(2,128,192,192,256,1),(2,64,96,96,128,1),(3,256,48,48,256,1),(2,128,48,48,128,2),(1,64,384,384,128,1),"
+        "(2,64,192,384,192,1),(4,64,48,16,128,1),(2,192,96,192,320,1),(1,64,24,32,128,2)]:\n"
+        "    g = torch.Generator().manual_seed(1)\n"
+        "    x = torch.randn(B,Cin,H,W,generator=g).bfloat16().float(); w = (torch.randn(Cout,Cin,3,3,generator=g)*0.05).bfloat16().float()\n"
+        "    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)\n"
+        "    yc = F.conv2d(xc, wc, None, 1, pad, pad); gy = torch.randn(yc.shape, generator=g).bfloat16().float(); yc.backward(gy)\n"
+        "    xd = x.cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True); wd = w.cuda().requires_grad_(True)\n"
+        "    yd = conv.conv2d(xd, wd, None, 1, pad, pad); yd.backward(gy.cuda().bfloat16().contiguous(memory_format=torch.channels_last))\n"
+        "    rel = lambda a, b: ((a.double().cpu()-b.double()).abs().max()/b.double().abs().max()).item()\n"
+        "    assert rel(yd, yc) < 1e-2 and rel(xd.grad, xc.grad) < 1e-2 and rel(wd.grad, wc.grad) < 2e-2, ((B,Cin,H,W,Cout,pad), rel(yd,yc), rel(xd.grad,xc.grad), rel(wd.grad,wc.grad))\n"
+        "    st, cnt, npix = yd._mrfp_colstats; S = st.view(cnt, 2, -1).double().sum(0); yf = yd.detach().double()\n"
+        "    assert npix == B*H*W and rel(S[0], yf.sum((0,2,3)).cpu()) < 1e-4 and rel(S[1], (yf*yf).sum((0,2,3)).cpu()) < 1e-4, ('stats', (B,Cin,H,W,Cout,pad))\n"
+        "    with torch.no_grad():\n"
+        "        ys = [conv.conv2d(xd.detach(), wd.detach(), None, 1, pad, pad).clone() for _ in range(4)]\n"
+        "    assert all(torch.equal(ys[0], y) for y in ys[1:]), (B,Cin,H,W,Cout,pad)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

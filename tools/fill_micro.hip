@@ -16,7 +16,8 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned lds_addr, unsi
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc));
 }
 
-template <int MODE>   // 0: LDS-DMA, 1: register loads (16 B per lane), 2: LDS-DMA + an MFMA stream beside it
+template <int MODE>   // 0: LDS-DMA, 1: register loads (16 B per lane), 2: LDS-DMA + an MFMA stream beside it, 3 / 4: LDS-DMA + 8 / 16
+                      // ds_read_b128 per wave and tile (2 / 4 bytes of fragment reads per byte filled), 5: 3 + the MFMA stream
 __global__ __launch_bounds__(256) void fill_kernel(const char* src, unsigned long long span, int iters, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -50,7 +51,18 @@ __global__ __launch_bounds__(256) void fill_kernel(const char* src, unsigned lon
                 dma16(r, lds0 + (unsigned)(((it & 1) * 16 + q * 4 + wave) * 1024), o);
             }
         }
-        if (MODE == 2) {
+        if (MODE >= 3) {
+            // fragment-read traffic from the OTHER half of the LDS (no ordering against the transfers needed for a rate test)
+            const char* rd = smem + 32768 + lane * 16;
+#pragma unroll
+            for (int m = 0; m < (MODE == 4 ? 16 : 8); ++m) {
+                unsigned __attribute__((ext_vector_type(4))) v;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)rd), "n"(m * 1024));
+                asm volatile("" :: "v"(v));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (MODE == 2 || MODE == 5) {
 #pragma unroll
             for (int m = 0; m < 16; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[m & 3], 0, 0, 0);
         }
@@ -125,9 +137,9 @@ static void run(const char* name, const char* d, unsigned long long span, int wp
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(fill_kernel<MODE>, dim3(grid), dim3(256), 32768, 0, d, span, iters / 8, sink);
+    hipLaunchKernelGGL(fill_kernel<MODE>, dim3(grid), dim3(256), 49152, 0, d, span, iters / 8, sink);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(fill_kernel<MODE>, dim3(grid), dim3(256), 32768, 0, d, span, iters, sink);
+    hipLaunchKernelGGL(fill_kernel<MODE>, dim3(grid), dim3(256), 49152, 0, d, span, iters, sink);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -145,12 +157,17 @@ int main() {
     hipMemset(d, 1, total + (1 << 20));
     hipDeviceSynchronize();
     const unsigned long long spans[] = {8192ull, 16384ull, 1ull << 21, 1ull << 24, total};
-    for (int wpc = 2; wpc <= 4; wpc += 2)
+    for (int wpc = 2; wpc <= 3; ++wpc)
         for (unsigned long long span : spans) {
             const int iters = span >= (1ull << 29) ? 512 : 2048;
             run<0>("LDS-DMA", d, span, wpc, iters, sink);
             run<1>("register loads", d, span, wpc, iters, sink);
             run<2>("LDS-DMA + 16 MFMA per tile", d, span, wpc, iters, sink);
+            if (span == (1ull << 21)) {
+                run<3>("LDS-DMA + 8 ds_read_b128", d, span, wpc, iters, sink);
+                run<4>("LDS-DMA + 16 ds_read_b128", d, span, wpc, iters, sink);
+                run<5>("LDS-DMA + 8 reads + 16 MFMA", d, span, wpc, iters, sink);
+            }
         }
     const unsigned strides[] = {128u, 256u, 512u, 640u, 1024u, 1152u, 2048u, 2176u, 4096u, 4224u};
     for (int wpc = 2; wpc <= 3; ++wpc)
