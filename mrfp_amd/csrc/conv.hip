@@ -1176,7 +1176,8 @@ static bool use_tile192(const ConvP& p, int esz) {
 //  29.3 us on the 1024 -> 256 pointwise layer -- fewer co-resident workgroups cost more than the fill bytes save)
 
 // Row-reuse kernels: the tile (192 or 96 rows; 0 = not applicable) a launch runs on.  MRFP_CONV_RR=0: off; 1: where the plain
-// kernel would run the same tile shape; 2: also instead of the 128x128 tile where a row-reuse tile fits.
+// kernel would run the 192x128 tile; 2 (default): also instead of the 128x128 / 96x128 tiles; 3: wherever 192 rows fit the image
+// geometry; 4: also the 96-row variant.
 static int g_rr = -1;
 static int rr_tile(const ConvP& p, int esz) {
     if (g_rr < 0) {
@@ -1192,9 +1193,14 @@ static int rr_tile(const ConvP& p, int esz) {
         const int PW = p.W < BM ? p.W : BM, RT = BM / PW;
         return RT * (PW + 2 * p.dil) <= BM + 32;
     };
-    if (use_tile192(p, esz)) return fits(192) ? 192 : 0;
-    if (g_rr >= 2 && fits(192)) return 192;
-    if (g_rr >= 3 && fits(96)) return 96;
+    // Where it pays (bench.py --dump-convs with the switch off / on, several boxes): long K (C >= 256: at least 12 patch fills
+    // per tile to amortise the 76 KB prologue), at least one full round of tiles at two workgroups per CU, and an N that does not
+    // waste most of its last 128-column tile.  Lost: M = 36 864, 256 -> 256 (384 tiles: 825 vs 880 TFLOP/s against the 96x128
+    // tile), C = 128 (862 vs 912), N = 304 (918 vs 977).  Mode 3 lifts these restrictions (A/B runs).
+    const int64_t t192 = (int64_t)(p.M / 192) * ((p.N + 127) / 128);
+    const bool pays = p.C >= 256 && t192 >= 512 && ((p.N + 127) / 128) * 128 - p.N <= 64;
+    if (fits(192) && (g_rr >= 3 || (pays && (g_rr >= 2 || use_tile192(p, esz))))) return 192;
+    if (g_rr >= 4 && fits(96)) return 96;
     return 0;
 }
 

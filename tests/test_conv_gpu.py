@@ -235,7 +235,8 @@ def test_row_reuse_kernels_in_subprocess():
     """conv_igemm_kernel<..., RR = true> (3x3, stride 1, pad = dilation: one fill of a haloed pixel patch serves the three taps of
     a filter row) on every tile geometry it supports -- a tile inside one image row (W = 384, 192), whole rows per tile (W = 96,
     48, 16), dilation 2, batch > 1 -- forward + dgrad (the same kernel on the flipped pack) against torch, and repeated
-    launches bit-identical.  MRFP_CONV_RR=2 routes every eligible shape to these kernels (read once per process)."""
+    launches bit-identical.  MRFP_CONV_RR=4 routes every shape that fits to these kernels (read once per process; the default
+    mode keeps them to the long-K layers where they pay)."""
     import os
     import subprocess
     import sys
@@ -259,6 +260,6 @@ def test_row_reuse_kernels_in_subprocess():
         "    assert all(torch.equal(ys[0], y) for y in ys[1:]), (B,Cin,H,W,Cout,pad)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="2")
+    env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="4")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
