@@ -152,53 +152,14 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
         for (int ih = j; ih < g.Hs; ih += ly) {
             const int oh0 = invH ? invH[2 * ih] : ih, oh1 = invH ? invH[2 * ih + 1] : ih + 1;
             const size_t sl = ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
-            for (int iw = trow; iw < g.Ws; iw += L.rowthreads) {
-                const int ow0 = invW ? invW[2 * iw] : iw, ow1 = invW ? invW[2 * iw + 1] : iw + 1;
+            const bool need_x = x && (Q || remask);
+            // one source pixel by the plain loops (any fan-in; y / dres supported)
+            auto slow_pixel = [&](int iw, int ow0, int ow1) {
                 float acc[VEC], xv[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { acc[i] = 0.f; xv[i] = 0.f; }
                 const float n = (float)((oh1 - oh0) * (ow1 - ow0));
-                if (KR > 0 && oh1 - oh0 <= KR && ow1 - ow0 <= KR) {
-                    // bounded fan-in (nearest resize by a small factor; launched only without y / dres): the KR*KR
-                    // candidate gradients are loaded unconditionally from clamped positions, all in flight together;
-                    // absent ones are masked out
-                    VecT<T, VEC> xr, dr[KR > 0 ? KR * KR : 1];
-                    const bool need_x = x && (Q || remask);
-                    if (need_x) xr = load_raw<T, VEC>(x + sl + (size_t)iw * g.C);
-#pragma unroll
-                    for (int kh = 0; kh < KR; ++kh) {
-                        const int oh = min(oh0 + kh, g.Ho - 1);
-                        const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
-#pragma unroll
-                        for (int kw = 0; kw < KR; ++kw)
-                            dr[kh * KR + kw] = load_raw<T, VEC>(dy + dl + (size_t)min(ow0 + kw, g.Wo - 1) * g.C);
-                    }
-                    if (need_x) cvt_f<T, VEC>(xr, xv);
-                    float keep[VEC];      // the ReLU mask depends on the source pixel only
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) keep[i] = (!remask || xv[i] * fa[i] + fs[i] > 0.f) ? 1.f : 0.f;
-#pragma unroll
-                    for (int kh = 0; kh < KR; ++kh)
-#pragma unroll
-                        for (int kw = 0; kw < KR; ++kw) {
-                            const bool have = oh0 + kh < oh1 && ow0 + kw < ow1;
-                            float dv[VEC];
-                            cvt_f<T, VEC>(dr[kh * KR + kw], dv);
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) acc[i] += (have && keep[i] != 0.f) ? dv[i] : 0.f;
-                        }
-                    float o[VEC];
-                    if (x && Q) {
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * (q[i] * xv[i] + r[i]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * r[i];
-                    }
-                    store_f<T, VEC>(dx + sl + (size_t)iw * g.C, o);
-                    continue;
-                }
-                if (x && (Q || remask)) load_f<T, VEC>(x + sl + (size_t)iw * g.C, xv);
+                if (need_x) load_f<T, VEC>(x + sl + (size_t)iw * g.C, xv);
                 for (int oh = oh0; oh < oh1; ++oh) {
                     const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
                     for (int ow = ow0; ow < ow1; ++ow) {
@@ -227,6 +188,79 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                     for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * r[i];
                 }
                 store_f<T, VEC>(dx + sl + (size_t)iw * g.C, o);
+            };
+            if constexpr (KR > 0) {
+                // bounded fan-in (nearest resize by a small factor; launched only without y / dres): U source pixels per trip,
+                // their index-table entries first, then every candidate gradient (KR*KR per pixel, loaded unconditionally from
+                // clamped positions; absent ones are masked out) and x -- all in flight together, converted on use.  (One
+                // pixel per trip left a dependent table -> gradient load chain exposed on every pixel: 3.2-3.7 TB/s.)
+                constexpr int U = KR == 1 ? 4 : 1;       // (KR = 2 with two pixels per trip: 314 vs 300 us)
+                for (int iw0 = trow; iw0 < g.Ws; iw0 += U * L.rowthreads) {
+                    int iwu[U], ow0[U], ow1[U];
+                    bool fast = oh1 - oh0 <= KR;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        iwu[u] = min(iw0 + u * L.rowthreads, g.Ws - 1);
+                        ow0[u] = invW[2 * iwu[u]];
+                        ow1[u] = invW[2 * iwu[u] + 1];
+                        fast = fast && ow1[u] - ow0[u] <= KR;
+                    }
+                    if (!fast) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            if (iw0 + u * L.rowthreads < g.Ws) slow_pixel(iwu[u], ow0[u], ow1[u]);
+                        continue;
+                    }
+                    VecT<T, VEC> xr[U], dr[U][KR * KR];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (need_x) xr[u] = KR == 1 ? load_raw_nt<T, VEC>(x + sl + (size_t)iwu[u] * g.C) : load_raw<T, VEC>(x + sl + (size_t)iwu[u] * g.C);
+#pragma unroll
+                        for (int kh = 0; kh < KR; ++kh) {
+                            const int oh = min(oh0 + kh, g.Ho - 1);
+                            const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
+#pragma unroll
+                            for (int kw = 0; kw < KR; ++kw)
+                                dr[u][kh * KR + kw] = KR == 1 ? load_raw_nt<T, VEC>(dy + dl + (size_t)min(ow0[u] + kw, g.Wo - 1) * g.C)
+                                                              : load_raw<T, VEC>(dy + dl + (size_t)min(ow0[u] + kw, g.Wo - 1) * g.C);
+                                // (KR > 1: the clamped candidates of neighbouring source pixels overlap -- the non-temporal policy
+                                //  evicted lines the next pixel re-reads: 300 -> 361 us)
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (iw0 + u * L.rowthreads >= g.Ws) continue;
+                        float acc[VEC], xv[VEC], keep[VEC];      // the ReLU mask depends on the source pixel only
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) { acc[i] = 0.f; xv[i] = 0.f; }
+                        if (need_x) cvt_f<T, VEC>(xr[u], xv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) keep[i] = (!remask || xv[i] * fa[i] + fs[i] > 0.f) ? 1.f : 0.f;
+#pragma unroll
+                        for (int kh = 0; kh < KR; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < KR; ++kw) {
+                                const bool have = oh0 + kh < oh1 && ow0[u] + kw < ow1[u];
+                                float dv[VEC];
+                                cvt_f<T, VEC>(dr[u][kh * KR + kw], dv);
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) acc[i] += (have && keep[i] != 0.f) ? dv[i] : 0.f;
+                            }
+                        const float n = (float)((oh1 - oh0) * (ow1[u] - ow0[u]));
+                        float o[VEC];
+                        if (x && Q) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * (q[i] * xv[i] + r[i]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) o[i] = p[i] * acc[i] + n * r[i];
+                        }
+                        store_f<T, VEC>(dx + sl + (size_t)iwu[u] * g.C, o);
+                    }
+                }
+            } else {
+                for (int iw = trow; iw < g.Ws; iw += L.rowthreads)
+                    slow_pixel(iw, invW ? invW[2 * iw] : iw, invW ? invW[2 * iw + 1] : iw + 1);
             }
         }
     }
