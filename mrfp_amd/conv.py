@@ -76,31 +76,24 @@ def get_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, Cphys: i
     return pk
 
 
-_BATCH = {"sig": None, "jobs": None, "prefix": None, "total": 0, "packs": None}
+_BATCH = {}
 
 
-def repack_all():
-    """Re-packs, in ONE launch, every cached bias-free pack whose fp32 master changed (called by the harness right after
-    the fused SGD kernel rewrote the parameter arena; 124 launches of ~7 us per step otherwise).  Packs with a bias
-    (final2) and packs of weights that are re-drawn on the host side (HRFP) keep the lazy per-layer path."""
+def _packable(pk, w):
+    return (w is not None and pk.bias is None and w.dtype == torch.float32 and w.is_contiguous()
+            and w.shape[2] * w.shape[3] <= 9)        # the brick kernel holds up to 3x3 taps; the 7x7 stem packs lazily
+
+
+def _batched_repack(todo, tag):
+    """ONE mrfp_pack_weights_batched launch per dtype for the (key, pack, weight) triples in `todo`; the job table is cached
+    per (tag, dtype) and rebuilt only when the set of packs changes."""
     import numpy as np
-    todo = []
-    for per_w in _PACKS.values():
-        for key, pk in per_w.items():
-            w = pk.wref() if getattr(pk, "wref", None) is not None else None
-            if w is None or pk.bias is not None or not w.requires_grad or w.dtype != torch.float32 or not w.is_contiguous():
-                continue
-            if w.shape[2] * w.shape[3] > 9:           # the brick kernel holds up to 3x3 taps; the 7x7 stem packs lazily
-                continue
-            todo.append((key, pk, w))
-    if not todo:
-        return
     by_dtype = {}
     for key, pk, w in todo:
         by_dtype.setdefault(key[0], []).append((key, pk, w))
     for dtype, items in by_dtype.items():
         sig = tuple((id(pk), w.data_ptr(), pk.wf.data_ptr(), pk.wd.data_ptr()) for _, pk, w in items)
-        st = _BATCH.get(dtype)
+        st = _BATCH.get((tag, dtype))
         if st is None or st["sig"] != sig:
             rec = np.zeros(len(items), dtype=np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("dims", "<i4", (6,))]))
             prefix = np.zeros(len(items) + 1, dtype=np.int64)
@@ -113,10 +106,40 @@ def repack_all():
             dev = items[0][2].device
             st = {"sig": sig, "jobs": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
                   "prefix": torch.from_numpy(prefix).to(dev), "total": int(prefix[-1]), "n": len(items)}
-            _BATCH[dtype] = st
+            _BATCH[(tag, dtype)] = st
         call("mrfp_pack_weights_batched", ptr(st["jobs"]), ptr(st["prefix"]), st["n"], st["total"], _lib._DT[dtype], stream())
-        for key, pk, w in items:
-            pk.version = (w._version, 0, _EPOCH[0])
+        if not torch.cuda.is_current_stream_capturing():
+            for key, pk, w in items:
+                pk.version = (w._version, 0, _EPOCH[0])
+
+
+def repack_all():
+    """Re-packs, in ONE launch, every cached bias-free pack whose fp32 master changed (called by the harness right after
+    the fused SGD kernel rewrote the parameter arena; 124 launches of ~7 us per step otherwise).  Packs with a bias
+    (final2) keep the lazy per-layer path; the frozen HRFP weights, re-drawn at the start of a forward, go through
+    repack_weights()."""
+    todo = []
+    for per_w in _PACKS.values():
+        for key, pk in per_w.items():
+            w = pk.wref() if getattr(pk, "wref", None) is not None else None
+            if w is None or not w.requires_grad or not _packable(pk, w):
+                continue
+            todo.append((key, pk, w))
+    if todo:
+        _batched_repack(todo, "trainable")
+
+
+def repack_weights(weights, tag="list"):
+    """The same for an explicit list of weights that were just rewritten (the HRFP branch's convolutions after their
+    re-initialisation: reference deepv3.py:290-299 re-draws them at the start of a forward; 28 pack launches per step
+    otherwise).  Weights without a cached pack yet are left to the lazy path."""
+    todo = []
+    for w in weights:
+        for key, pk in _PACKS.get(id(w), {}).items():
+            if _packable(pk, w) and pk.wf is not None:
+                todo.append((key, pk, w))
+    if todo:
+        _batched_repack(todo, tag)
 
 
 def _out_size(H, R, stride, pad, dil):

@@ -490,6 +490,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || RR ? 2 : 3)) void co
         const int PW = p.W < BM ? p.W : BM, RT = BM / PW, PWH = PW + 2 * dil;
         const int hw = p.H * p.W;
         const int b0 = m0 / hw, rem0 = m0 - b0 * hw, oh0 = rem0 / p.W, ow0 = rem0 - oh0 * p.W;
+        // The patch is read at EVERY row offset (tap shifts), not only at multiples of 16: its chunk swizzle is keyed by row & 7
+        // (conflict-free for ds_read_b128 of 16 consecutive rows from any start row; the tiles' (row >> 1) & 7 key is so only from
+        // multiples of 4 -- SQ_LDS_BANK_CONFLICT was 5 % of the wave cycles with it).
+        const int chunk_a = (t & 7) ^ (rbase & 7);
+        auto lds_off_a = [](int row, int ch) { return row * 128 + (((ch ^ row) & 7) << 4); };
         unsigned r_j = 0, r_okm = 0;   // per piece i: image row j of its patch row (4 bits each) and "inside the image row" bit
         unsigned r_base[SAR];   // byte offset of its pixel at filter row r = 1 (the centre row), chunk included
 #pragma unroll
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || RR ? 2 : 3)) void co
             const bool ok = j < RT && col >= 0 && col < p.W;
             r_j |= (unsigned)(j & 15) << (4 * i);
             r_okm |= (ok ? 1u : 0u) << i;
-            r_base[i] = (unsigned)((b0 * p.H + oh0 + j) * p.W + col) * (unsigned)pixbytes + (unsigned)(chunk * 16);
+            r_base[i] = (unsigned)((b0 * p.H + oh0 + j) * p.W + col) * (unsigned)pixbytes + (unsigned)(chunk_a * 16);
         }
         auto fill_a = [&](int cc, int r) {
             const int dh = (r - 1) * dil;
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || RR ? 2 : 3)) void co
             const int sh = s_ * dil + l15;
             const char* bt = sBr + s_ * (BN * 128);
 #pragma unroll
-            for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA0 + lds_off(arow[i] + sh, ch));
+            for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA0 + lds_off_a(arow[i] + sh, ch));
 #pragma unroll
             for (int j = 0; j < 2 * TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(bt + lds_off(wn * 32 * TN + j * 16 + l15, ch));
         };

@@ -44,6 +44,8 @@ class ReferenceRandom:
         for conv, bn in model.hrfp_layers():
             initialize_weights_kaimingnormal_forOC(conv)
             initialize_weights_kaimingnormal_forOC(bn)
+        from . import conv as conv_mod
+        conv_mod.repack_weights([c.weight for c, _ in model.hrfp_layers()], tag="hrfp")   # one pack launch instead of one per layer
 
     def np_noise(self, which, B, C, device):
         # torch.normal(mean_tensor, std_tensor) as the reference calls it (deepv3.py:274-275) is, inside ATen,
