@@ -58,6 +58,11 @@ int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* me
                    const float* fA, const float* fS, int per_image, int dtype, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
                    int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW,
                    float* ws, void* stream);
+/* The same with the ReLU gate read from a SIGN MASK (1 bit per element, bit i of byte e/8 = element e of the dense [B,H,W,C]
+ * tensor, written by mrfp_affine_fwd_relu_mask) instead of y: the backward of a residual block's BatchNorm -> add -> ReLU tail
+ * (reference Resnet.py:202-225) needs only the sign of its output.  16-bit activations, C % 8 == 0, identity geometry. */
+int mrfp_stats_bwd_mask(const void* dy, const void* x, const void* mask, const float* mean, int per_image, int dtype, int64_t B,
+                        int64_t H, int64_t W, int64_t C, float* ws, void* stream);
 
 /* BatchNorm (train): statistics over B*Ho*Wo; biased var for normalisation, unbiased for the
  * running update (momentum).  Outputs mean[C], invstd[C] and the apply coefficients
@@ -124,6 +129,12 @@ int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void
                     const int32_t* invH, const int32_t* invW,
                     const float* P, const float* Q, const float* R,
                     const float* fA, const float* fS, int coef_per_image, void* stream);
+/* y = relu(x*A + S + res) AND its sign mask (see mrfp_stats_bwd_mask); the matching backward apply reads the mask where
+ * mrfp_affine_bwd reads y (dres = the masked gradient, for the skip connection). */
+int mrfp_affine_fwd_relu_mask(const void* x, const void* res, void* y, void* mask, int dtype, int64_t B, int64_t H, int64_t W,
+                              int64_t C, const float* A, const float* S, int coef_per_image, void* stream);
+int mrfp_affine_bwd_mask(const void* dy, const void* x, const void* mask, void* dx, void* dres, int dtype, int64_t B, int64_t H,
+                         int64_t W, int64_t C, const float* P, const float* Q, const float* R, int coef_per_image, void* stream);
 
 /* dst[p][c0_dst + c] = src[p][c0_src + c], c < C, over npix pixels of NHWC tensors with channel pitches ld_src / ld_dst:
  * torch.cat((...), 1) of reference deepv3.py:125, 353 (one call per input) and its backward (one call per slice). */

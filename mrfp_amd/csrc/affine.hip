@@ -14,7 +14,7 @@ template <typename T, int VEC, bool RESIZE>
 __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                               T* __restrict__ y, RowGeom g, int ly,
                                                               const float* __restrict__ A, const float* __restrict__ S,
-                                                              int coef_per_image, int relu) {
+                                                              int coef_per_image, int relu, uint8_t* __restrict__ mask_out) {
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
     const Lanes L = make_lanes(g.C, VEC);
     const int t = threadIdx.x;
@@ -71,6 +71,16 @@ __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restric
                         for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
                     }
                     store_f<T, VEC>(y + dl + (size_t)ow * g.C, v);
+                    if constexpr (VEC == 8) {
+                        // sign mask of the STORED (rounded) output, one bit per element: what the backward passes of a residual
+                        // block need of y (the ReLU gate) at 1/16 of its bytes
+                        if (mask_out) {
+                            unsigned m = 0;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) m |= (to_f(from_f<T>(v[i])) > 0.f ? 1u : 0u) << i;
+                            mask_out[(dl + (size_t)ow * g.C) >> 3] = (uint8_t)m;
+                        }
+                    }
                 }
             }
         }
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restric
 // Backward, walking SOURCE lines.  invH[2*ih], invH[2*ih+1] = half-open range of destination rows that
 // read source row ih (NULL = identity).  dres (destination geometry) is only supported with
 // identity maps (the residual branches of the network never sit behind a resize).
-template <typename T, int VEC, int KR>
+template <typename T, int VEC, int KR, bool YM = false>      // YM: `y` is the 1-bit-per-element sign mask written by affine_fwd_kernel
 __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                               const T* __restrict__ y, T* __restrict__ dx,
                                                               T* __restrict__ dres, RowGeom g, int ly,
@@ -114,12 +124,14 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
                 const size_t sl = ((size_t)b * g.Hs + ih) * g.Ws * g.C + (size_t)cv * VEC;
                 for (int iw0 = trow; iw0 < g.Ws; iw0 += 4 * L.rowthreads) {
                     VecT<T, VEC> dr[4], xr[4], yr[4];
+                    unsigned mb[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {      // unconditional, clamped (see stats.hip)
                         const int iw = min(iw0 + u * L.rowthreads, g.Ws - 1);
                         dr[u] = load_raw_nt<T, VEC>(dy + sl + (size_t)iw * g.C);
                         if (x && (Q || remask)) xr[u] = load_raw_nt<T, VEC>(x + sl + (size_t)iw * g.C);
-                        if (y) yr[u] = load_raw_nt<T, VEC>(y + sl + (size_t)iw * g.C);
+                        if constexpr (YM) mb[u] = reinterpret_cast<const uint8_t*>(y)[(sl + (size_t)iw * g.C) >> 3];
+                        else if (y) yr[u] = load_raw_nt<T, VEC>(y + sl + (size_t)iw * g.C);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -130,7 +142,10 @@ __global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const T* __restric
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) xv[i] = 0.f;
                         if (x && (Q || remask)) cvt_f<T, VEC>(xr[u], xv);
-                        if (y) {
+                        if constexpr (YM) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) dv[i] = ((mb[u] >> i) & 1u) ? dv[i] : 0.f;
+                        } else if (y) {
                             float yv[VEC];
                             cvt_f<T, VEC>(yr[u], yv);
 #pragma unroll
@@ -332,17 +347,18 @@ static int launch_copy_channels(const void* src, void* dst, int64_t npix, int64_
 template <typename T>
 static int launch_affine_fwd(const void* x, const void* res, void* y, int64_t B, int64_t Ho, int64_t Wo, int64_t C,
                              int64_t Hs, int64_t Ws, const int32_t* tabH, const int32_t* tabW, const float* A,
-                             const float* S, int cpi, int relu, hipStream_t st) {
+                             const float* S, int cpi, int relu, hipStream_t st, uint8_t* mask_out = nullptr) {
     RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, tabH, tabW};
     const int ly = lines_per_image(B, Ho);
     dim3 grid((unsigned)(B * ly));
     const bool vec_ok = pick_vec<T>(C) > 1 && (!x || aligned16(x)) && aligned16(y) && (!res || aligned16(res)) &&
                         (!A || aligned16(A)) && (!S || aligned16(S));
+    if (mask_out && !(vec_ok && FullVec<T>::value == 8)) { set_error("affine_fwd_mask: 16-bit activations with C %% 8 == 0, 16-byte aligned"); return -1; }
     const bool resize = tabH != nullptr || tabW != nullptr;
     if (resize && !(tabH && tabW)) { set_error("affine_fwd: both index tables or none"); return -1; }
 #define MRFP_AFF_LAUNCH(VECV, RS)                                                                                      \
     hipLaunchKernelGGL((affine_fwd_kernel<T, VECV, RS>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)res,      \
-                       (T*)y, g, ly, A, S, cpi, relu)
+                       (T*)y, g, ly, A, S, cpi, relu, mask_out)
     if (vec_ok) { if (resize) MRFP_AFF_LAUNCH(FullVec<T>::value, true); else MRFP_AFF_LAUNCH(FullVec<T>::value, false); }
     else { if (resize) MRFP_AFF_LAUNCH(1, true); else MRFP_AFF_LAUNCH(1, false); }
 #undef MRFP_AFF_LAUNCH
@@ -354,7 +370,7 @@ template <typename T>
 static int launch_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t B, int64_t Ho,
                              int64_t Wo, int64_t C, int64_t Hs, int64_t Ws, const int32_t* invH, const int32_t* invW,
                              const float* P, const float* Q, const float* R, const float* fA, const float* fS, int cpi,
-                             hipStream_t st) {
+                             hipStream_t st, bool ymask = false) {
     RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, nullptr, nullptr};
     const int ly = lines_per_image(B, Hs);
     dim3 grid((unsigned)(B * ly));
@@ -373,6 +389,18 @@ static int launch_affine_bwd(const void* dy, const void* x, const void* y, void*
     hipLaunchKernelGGL((affine_bwd_kernel<T, VECV, KRV>), grid, dim3(kThreads), 0, st, (const T*)dy, (const T*)x,      \
                        (const T*)y, (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, fA, fS, cpi)
     const bool identity = !invH && !invW;
+    if (ymask) {
+        if constexpr (FullVec<T>::value == 8) {
+            if (!(vec_ok && identity && y)) { set_error("affine_bwd_mask: 16-bit activations, C %% 8 == 0, identity geometry"); return -1; }
+            hipLaunchKernelGGL((affine_bwd_kernel<T, 8, -1, true>), grid, dim3(kThreads), 0, st, (const T*)dy, (const T*)x, (const T*)y,
+                               (T*)dx, (T*)dres, g, ly, invH, invW, P, Q, R, fA, fS, cpi);
+            MRFP_LAUNCH_CHECK();
+            return 0;
+        } else {
+            set_error("affine_bwd_mask: 16-bit activations only");
+            return -1;
+        }
+    }
     if (vec_ok) {
         if (identity) MRFP_AFFB_LAUNCH(FullVec<T>::value, -1);
         else if (kr == 1) MRFP_AFFB_LAUNCH(FullVec<T>::value, 1);
@@ -441,6 +469,24 @@ int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void
     if (dtype == MRFP_BF16) return launch_affine_bwd<bf16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
     if (dtype == MRFP_F16) return launch_affine_bwd<f16>(dy, x, y, dx, dres, B, Ho, Wo, C, Hs, Ws, invH, invW, P, Q, R, fA, fS, coef_per_image, st);
     MRFP_CHECK(false, "affine_bwd: unknown dtype %d", dtype);
+}
+
+int mrfp_affine_fwd_relu_mask(const void* x, const void* res, void* y, void* mask, int dtype, int64_t B, int64_t H, int64_t W,
+                              int64_t C, const float* A, const float* S, int coef_per_image, void* stream) {
+    MRFP_CHECK(x && y && mask && A && S && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "affine_fwd_relu_mask: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_BF16) return launch_affine_fwd<bf16>(x, res, y, B, H, W, C, H, W, nullptr, nullptr, A, S, coef_per_image, 1, st, (uint8_t*)mask);
+    if (dtype == MRFP_F16) return launch_affine_fwd<f16>(x, res, y, B, H, W, C, H, W, nullptr, nullptr, A, S, coef_per_image, 1, st, (uint8_t*)mask);
+    MRFP_CHECK(false, "affine_fwd_relu_mask: 16-bit activations only (dtype %d)", dtype);
+}
+
+int mrfp_affine_bwd_mask(const void* dy, const void* x, const void* mask, void* dx, void* dres, int dtype, int64_t B, int64_t H,
+                         int64_t W, int64_t C, const float* P, const float* Q, const float* R, int coef_per_image, void* stream) {
+    MRFP_CHECK(dy && dx && mask && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "affine_bwd_mask: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_BF16) return launch_affine_bwd<bf16>(dy, x, mask, dx, dres, B, H, W, C, H, W, nullptr, nullptr, P, Q, R, nullptr, nullptr, coef_per_image, st, true);
+    if (dtype == MRFP_F16) return launch_affine_bwd<f16>(dy, x, mask, dx, dres, B, H, W, C, H, W, nullptr, nullptr, P, Q, R, nullptr, nullptr, coef_per_image, st, true);
+    MRFP_CHECK(false, "affine_bwd_mask: 16-bit activations only (dtype %d)", dtype);
 }
 
 int mrfp_copy_channels(const void* src, void* dst, int dtype, int64_t npix, int64_t C, int64_t ld_src, int64_t c0_src,

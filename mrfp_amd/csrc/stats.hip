@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 // MODE 0: s += x, q += x*x                         (forward statistics)
 // MODE 1: s += dy', q += dy'*(x - mean[g,c])       (backward statistics; dy' masked by y > 0)
 // ------------------------------------------------------------------------------------------
-template <typename T, int VEC, int MODE, bool RESIZE>
+template <typename T, int VEC, int MODE, bool RESIZE, bool YM = false>     // YM: `y` is the 1-bit-per-element sign mask (affine.hip)
 __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ fA, const float* __restrict__ fS,
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
                     // below): a load inside a divergent `if (ow < Wo)` region is waited for at the region's end
                     // (s_waitcnt vmcnt(0) per pixel), which leaves 2-3 loads in flight instead of 8-12
                     VecT<T, VEC> xr[4], dr[4], yr[4];
+                    unsigned mb[4] = {0u, 0u, 0u, 0u};
                     int owc[4], iwv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -78,11 +79,12 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
                         xr[u] = load_raw<T, VEC>(xl + (size_t)iwv[u] * g.C);
                         if (MODE == 1) {
                             dr[u] = load_raw<T, VEC>(dy + dl + (size_t)owc[u] * g.C);
-                            if (y != nullptr) yr[u] = load_raw<T, VEC>(y + dl + (size_t)owc[u] * g.C);
+                            if constexpr (YM) mb[u] = reinterpret_cast<const uint8_t*>(y)[(dl + (size_t)owc[u] * g.C) >> 3];
+                            else if (y != nullptr) yr[u] = load_raw<T, VEC>(y + dl + (size_t)owc[u] * g.C);
                         }
                     }
                     // branch-free arithmetic: the line tail and the ReLU mask are selects, not divergent regions
-                    const bool use_y = MODE == 1 && y != nullptr;
+                    const bool use_y = MODE == 1 && y != nullptr && !YM;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const bool inside = ow0 + u * L.rowthreads < g.Wo;
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
                             }
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) {
-                                const float gate = use_y ? yv[i] : (remask ? xv[i] * fa[i] + fs[i] : 1.f);
+                                const float gate = YM ? (((mb[u] >> i) & 1u) ? 1.f : 0.f)
+                                                      : use_y ? yv[i] : (remask ? xv[i] * fa[i] + fs[i] : 1.f);
                                 const float d = (inside && gate > 0.f) ? dv[i] : 0.f;
                                 s[i] += d;
                                 q[i] += d * (xv[i] - mu[i]);
@@ -141,13 +144,25 @@ template <typename T, int MODE>
 static int launch_stats(const void* x, const void* dy, const void* y, const float* mean, const float* fA,
                         const float* fS, int per_image,
                         int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
-                        const int32_t* tabH, const int32_t* tabW, float* ws, hipStream_t st) {
+                        const int32_t* tabH, const int32_t* tabW, float* ws, hipStream_t st, bool ymask = false) {
     RowGeom g{(int)B, (int)Ho, (int)Wo, (int)C, (int)Hs, (int)Ws, tabH, tabW};
     const int ly = lines_per_image(B, Ho);
     dim3 grid((unsigned)(B * ly));
-    const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(x) && (MODE == 0 || (aligned16(dy) && (y == nullptr || aligned16(y))));
+    const bool vec_ok = pick_vec<T>(C) > 1 && aligned16(x) && (MODE == 0 || (aligned16(dy) && (y == nullptr || ymask || aligned16(y))));
     const bool resize = tabH != nullptr || tabW != nullptr;
     if (resize && !(tabH && tabW)) { set_error("stats: both index tables or none"); return -1; }
+    if (ymask) {
+        if constexpr (MODE == 1 && FullVec<T>::value == 8) {
+            if (!(vec_ok && !resize && y)) { set_error("stats_bwd_mask: 16-bit activations, C %% 8 == 0, identity geometry"); return -1; }
+            hipLaunchKernelGGL((stats_kernel<T, 8, 1, false, true>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean,
+                               fA, fS, per_image, g, ly, ws);
+            MRFP_LAUNCH_CHECK();
+            return 0;
+        } else {
+            set_error("stats_bwd_mask: 16-bit activations only");
+            return -1;
+        }
+    }
 #define MRFP_STATS_LAUNCH(VECV, RS)                                                                                    \
     hipLaunchKernelGGL((stats_kernel<T, VECV, MODE, RS>), grid, dim3(kThreads), 0, st, (const T*)x, (const T*)dy,      \
                        (const T*)y, mean, fA, fS, per_image, g, ly, ws)
@@ -469,6 +484,15 @@ int mrfp_stats_bwd(const void* dy, const void* x, const void* y, const float* me
     if (dtype == MRFP_BF16) return launch_stats<bf16, 1>(x, dy, y, mean, fA, fS, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     if (dtype == MRFP_F16) return launch_stats<f16, 1>(x, dy, y, mean, fA, fS, per_image, B, Ho, Wo, C, Hs, Ws, tabH, tabW, ws, st);
     MRFP_CHECK(false, "stats_bwd: unknown dtype %d", dtype);
+}
+
+int mrfp_stats_bwd_mask(const void* dy, const void* x, const void* mask, const float* mean, int per_image, int dtype, int64_t B,
+                        int64_t H, int64_t W, int64_t C, float* ws, void* stream) {
+    MRFP_CHECK(dy && x && mask && ws && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "stats_bwd_mask: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRFP_BF16) return launch_stats<bf16, 1>(x, dy, mask, mean, nullptr, nullptr, per_image, B, H, W, C, H, W, nullptr, nullptr, ws, st, true);
+    if (dtype == MRFP_F16) return launch_stats<f16, 1>(x, dy, mask, mean, nullptr, nullptr, per_image, B, H, W, C, H, W, nullptr, nullptr, ws, st, true);
+    MRFP_CHECK(false, "stats_bwd_mask: 16-bit activations only (dtype %d)", dtype);
 }
 
 int mrfp_bn_finalize(const float* ws, int64_t B, int64_t nslab, int64_t count, int64_t C, const float* weight,

@@ -9,6 +9,7 @@ an activation goes through a hand-written HIP kernel, and a missing library rais
 from __future__ import annotations
 
 import math
+import os
 from functools import lru_cache
 from typing import Optional, Tuple
 
@@ -173,6 +174,9 @@ def _affine_bwd(dy, x, y, P, Q, R, per_image, plan, want_dres, like, fA=None, fS
 # ------------------------------------------------------------------------------------------
 # BatchNorm (+ nearest resize in front) (+ residual) (+ ReLU)
 # ------------------------------------------------------------------------------------------
+SIGN_MASK = [os.environ.get("MRFP_SIGN_MASK", "1") != "0"]     # residual BatchNorm+ReLU: 1-bit sign mask instead of y in backward
+
+
 class _BatchNormAct(torch.autograd.Function):
     """y = act(BN(resize(x)) + res).  reference: Norm2d/SyncBatchNorm on one process = F.batch_norm
     (mynn.py:19-25), Bottleneck tail (Resnet.py:202-225), HRFP stage (deepv3.py:320-327)."""
@@ -202,15 +206,24 @@ class _BatchNormAct(torch.autograd.Function):
             if x.requires_grad or (weight is not None and weight.requires_grad):
                 mean.copy_(running_mean)                          # what the backward's x-hat is built from
                 torch.rsqrt(running_var.float() + eps, out=invstd)
-        y = _affine_fwd(x, res, A, S, False, relu, plan)
         ctx.plan, ctx.relu, ctx.training, ctx.has_res = plan, relu, training, res is not None
         # ReLU mask for backward: without a residual it is recomputed from x and the apply coefficients
         # ((x*A+S) > 0, bit-identical to the forward expression), so y is not read again; with a residual the
-        # stored output is the only place the sign lives.
+        # stored output is the only place the sign lives -- and the two backward passes need nothing else of y, so
+        # the apply pass also writes its sign as ONE BIT per element (16-bit activations): they then read 1/16 of y's
+        # bytes (3.7 GB of y per step of the bench workload, read twice).
         keep_y = relu and res is not None
         ctx.remask = relu and res is None
+        ctx.ymask = bool(keep_y and plan is None and SIGN_MASK[0] and x.element_size() == 2 and C % 8 == 0)
+        if ctx.ymask:
+            y = empty_cl(B, C, Ho, Wo, x.dtype, dev)
+            mask = torch.empty(B * Ho * Wo * C // 8, dtype=torch.uint8, device=dev)
+            call("mrfp_affine_fwd_relu_mask", ptr(x), ptr(res), ptr(y), ptr(mask), dt(x), B, Ho, Wo, C, ptr(A), ptr(S), 0, stream())
+        else:
+            y = _affine_fwd(x, res, A, S, False, relu, plan)
+            mask = None
         ctx.wparam, ctx.bparam = weight, bias
-        ctx.save_for_backward(x, y if keep_y else None, w32, mean, invstd, A, S)
+        ctx.save_for_backward(x, (mask if ctx.ymask else y) if keep_y else None, w32, mean, invstd, A, S)
         if plan is None and (x.requires_grad or (weight is not None and weight.requires_grad)):
             # the convolution that consumes y can produce this layer's backward statistics in its dgrad epilogue
             # (mrfp_amd/conv.py, mrfp_conv_dgrad_bnstats); the token ties those statistics to THIS layer
@@ -238,6 +251,10 @@ class _BatchNormAct(torch.autograd.Function):
             ws, nb_, nslab = fused[0], 1, fused[1]
             from . import conv as _conv
             _conv.FUSED_BN_BWD_HITS[1] += 1
+        elif ctx.ymask:                    # y holds the sign mask
+            nslab, ws = _stats_ws(B, Ho, C, x.device)
+            call("mrfp_stats_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(mean), 0, dt(x), B, Ho, Wo, C, ptr(ws), stream())
+            nb_ = B
         else:
             nslab, ws = _stats_bwd(dy, x, y, mean, False, plan, fA, fS)
             nb_ = B
@@ -252,7 +269,13 @@ class _BatchNormAct(torch.autograd.Function):
             # gradient is just dy' * weight * invstd -- the batch-statistics terms Q, R vanish
             Q.zero_()
             R.zero_()
-        dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x, fA, fS)
+        if ctx.ymask:
+            dx = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
+            dres = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
+            call("mrfp_affine_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(dx), ptr(dres), dt(dy), B, Ho, Wo, C, ptr(P), ptr(Q), ptr(R), 0,
+                 stream())
+        else:
+            dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x, fA, fS)
         if sw is not None:
             notify_grad(ctx.wparam)
             dw = None

@@ -400,3 +400,35 @@ def test_bn_backward_statistics_from_the_dgrad_epilogue(dtype, tol, case):
             assert (f - r_).abs().max().item() <= tol * scale, name
         else:       # bf16 activations flip the ReLU mask of a few near-zero pre-activations: compare in the L2 norm
             assert ((f - r_).norm() / r_.norm()).item() <= 2.5 * tol, name
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 9, 7), (3, 256, 12, 10), (1, 1024, 5, 6)])
+def test_residual_bn_relu_sign_mask_equals_reading_y(dtype, shape):
+    """The residual BatchNorm -> add -> ReLU tail (reference Resnet.py:202-225) keeps ONE BIT per output element for its
+    backward (mrfp_affine_fwd_relu_mask / mrfp_stats_bwd_mask / mrfp_affine_bwd_mask) instead of re-reading y in both backward
+    passes: outputs and every gradient must be bit-identical with the path that reads y (ops.SIGN_MASK off), including
+    elements that are exactly zero after rounding."""
+    o = ops()
+    B, C, H, W = shape
+    x = rnd(*shape, seed=11, scale=2.0)
+    r = rnd(*shape, seed=12)
+    r[0, :, 0, 0] = -1e30                         # a clamped pixel
+    r[-1, :, -1, -1] = 0.0
+    w, b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    gy = rnd(*shape, seed=13)
+    outs = []
+    for use_mask in (True, False):
+        o.SIGN_MASK[0] = use_mask
+        try:
+            xd, rd = dev(x, dtype), dev(r, dtype)
+            wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            yd = o.batch_norm_act(xd, wd, bd, rm, rv, training=True, relu=True, res=rd)
+            yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+            outs.append((yd.detach().clone(), xd.grad.clone(), rd.grad.clone(), wd.grad.clone(), bd.grad.clone()))
+        finally:
+            o.SIGN_MASK[0] = True
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+    assert (outs[0][0] == 0).any() and (outs[0][0] > 0).any()
