@@ -246,6 +246,14 @@ int mrfp_conv_single_launch(int64_t B, int64_t image_bytes);
 int64_t mrfp_conv_stats_rows(int64_t nblk);
 int64_t mrfp_conv_stats_final_first(int64_t nblk);
 int64_t mrfp_conv_stats_final_count(int64_t nblk);
+/* mrfp_conv_fwd with a GATED addend: y = conv(x) + (addend where its gate bit is set, else 0).  addend_mask holds one bit per
+ * element of the dense [M][N] addend (bit e & 7 of byte e >> 3, e = m*N + n) -- the sign mask mrfp_affine_fwd_relu_mask wrote for
+ * the residual tail whose incoming gradient `addend` is: the skip-connection gradient dy * [y > 0] (reference: autograd of
+ * `out += residual; out = relu(out)`, Resnet.py:214-225) is then never materialised.  16-bit activations, N % 8 == 0, ldy == N. */
+int mrfp_conv_fwd_gated(const void* x, const void* wpack, const float* bias, void* y, int dtype,
+                        int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,
+                        int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil,
+                        int64_t sstride, const void* addend, const void* addend_mask, void* stream);
 /* dgrad that feeds a BatchNorm backward (reference: autograd of Norm2d -> ReLU -> nn.Conv2d chains, Resnet.py:202-216):
  * dx[B,Ho,Wo,0:N] = dgrad(dy[B,H,W,C], wd pack) (+ addend) as mrfp_conv_fwd with stride 1 / source stride `sstride`, and in
  * the SAME launch the BatchNorm-backward statistics of dx, which is dL/d(BN output): per row block

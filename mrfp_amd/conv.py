@@ -192,6 +192,23 @@ def join_wgrad_stream(stream=None):
         _WGRAD_PENDING[0] = False
 
 
+GATED_SKIP_HITS = [0]       # dgrad launches that applied a residual tail's gate to their addend (tests)
+
+
+def ungate(t):
+    """The plain gradient for a tensor that carries a `_mrfp_gate` (sign mask, version) tag: t * [mask bit set].  Tensors
+    without the tag (and None) pass through."""
+    g = getattr(t, "_mrfp_gate", None) if t is not None else None
+    if g is None:
+        return t
+    if g[1] != t._version:
+        raise _lib.MrfpHipError("a gated skip gradient was modified in place before it reached its consumer")
+    B, C, H, W = t.shape
+    out = empty_cl(B, C, H, W, t.dtype, t.device)
+    call("mrfp_affine_bwd_mask", ptr(t), None, ptr(g[0]), ptr(out), None, dt(t), B, H, W, C, None, None, None, 0, stream())
+    return out
+
+
 class _Conv2d(torch.autograd.Function):
     """want_skip: also return an alias of x for a skip connection; the gradient arriving on that alias is added by
     the dgrad kernel's epilogue (no separate accumulation pass over the activation)."""
@@ -230,7 +247,7 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, dy, dskip=None):
         x, weight, bias = ctx.saved_tensors
         if dy is None:            # only the skip alias was used downstream
-            return dskip, None, None, None, None, None, None, None, None
+            return ungate(dskip), None, None, None, None, None, None, None, None
         stride, pad_h, pad_w, dil, Nphys, Ho, Wo = ctx.cfg
         dy = _chk(dy, "dy")
         B, Cphys, H, W = x.shape
@@ -241,15 +258,27 @@ class _Conv2d(torch.autograd.Function):
                 raise _lib.MrfpHipError("dgrad through a channel-padded input is not supported")
             pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
             dx = empty_cl(B, Cphys, H, W, x.dtype, x.device)
+            bn = ctx.bn
+            L = _lib.lib()
+            use_bnstats = bool(bn is not None and bn["x"].shape == dx.shape and bn["x"].dtype == dx.dtype and
+                               L.mrfp_conv_dgrad_bnstats_ok(dt(dy), Nphys, Cphys) and
+                               L.mrfp_conv_single_launch(B, Ho * Wo * Nphys * dy.element_size()))
+            gate = None
             if dskip is not None:
+                g = getattr(dskip, "_mrfp_gate", None)
+                if g is not None:
+                    # the skip-connection gradient of a residual tail arrives UNMASKED with that tail's sign mask attached
+                    # (ops._BatchNormAct.backward): the dgrad epilogue applies the gate while it adds -- dy * [y > 0] is never
+                    # written or re-read.  Anything this launch cannot do that way gets the plain gradient.
+                    if (not use_bnstats and g[1] == dskip._version and dskip.dtype == x.dtype and x.element_size() == 2
+                            and Cphys % 8 == 0 and dskip.shape == dx.shape and dskip.is_contiguous(memory_format=CL)):
+                        gate = g[0]
+                    else:
+                        dskip = ungate(dskip)
                 dskip = _chk(dskip, "dskip")
                 if dskip.dtype != x.dtype:
                     dskip = dskip.to(x.dtype)
-            bn = ctx.bn
-            L = _lib.lib()
-            if bn is not None and bn["x"].shape == dx.shape and bn["x"].dtype == dx.dtype and \
-                    L.mrfp_conv_dgrad_bnstats_ok(dt(dy), Nphys, Cphys) and \
-                    L.mrfp_conv_single_launch(B, Ho * Wo * Nphys * dy.element_size()):
+            if use_bnstats:
                 # dx is dL/d(BatchNorm output): its backward statistics come out of this launch's epilogue
                 nblk = int(L.mrfp_conv_stats_blocks(dt(dy), B, Ho, Wo, Nphys, Cphys, R, S, H, W, 1, dil * (R - 1) - pad_h,
                                                      dil * (S - 1) - pad_w, dil, stride, 1))
@@ -262,6 +291,10 @@ class _Conv2d(torch.autograd.Function):
                 #  gradient into this tensor in place before handing it on)
                 dx._mrfp_bnstats = (st[first * 2 * Cphys:(first + cnt) * 2 * Cphys], cnt, bn["token"], dx._version)
                 FUSED_BN_BWD_HITS[0] += 1
+            elif gate is not None:
+                call("mrfp_conv_fwd_gated", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
+                     1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), ptr(gate), stream())
+                GATED_SKIP_HITS[0] += 1
             else:
                 call("mrfp_conv_fwd", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
                      1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), None, stream())
@@ -418,6 +451,8 @@ def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] =
     _LAST_STATS[0] = None
     out = _Conv2d.apply(x, weight, bias, st, ph, pw, dl, Nphys, want_skip)
     y, skip = out if want_skip else (out, None)
+    if skip is not None:
+        skip._mrfp_skip_alias = True      # its gradient goes to this convolution's dgrad epilogue and nowhere else
     if _LAST_STATS[0] is not None and (phys_out is not None or Nphys == N):
         y._mrfp_colstats = _LAST_STATS[0]        # consumed by ops.batch_norm_act (statistics pass skipped)
     _LAST_STATS[0] = None

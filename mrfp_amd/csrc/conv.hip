@@ -37,6 +37,9 @@ struct ConvP {
     char* y;            // output [M][ldy]
     const float* bias;  // [N] or null
     const char* addend; // [M][ldy] (T) added to the result in the epilogue, or null (fused gradient accumulation)
+    const unsigned char* addend_mask;   // or null: 1 bit per addend element (bit e & 7 of byte e >> 3, e = m*ldy + n): the addend is
+                        // taken as 0 where the bit is clear -- the ReLU gate of a residual tail applied while its gradient is
+                        // added (16-bit types, N % 8 == 0, dense ldy)
     float* colstats;    // [row blocks][2][ldy] per-channel sum / sum of squares of the stored output, or null
     // BNB kernels (dgrad feeding a BatchNorm backward): the stored output is dL/d(BN output); its BatchNorm-backward
     // statistics  sum g'  and  sum g' * (x - mean)  with  g' = g * [ReLU mask]  are produced here, per row block, instead
@@ -275,6 +278,15 @@ template <typename T> __device__ __forceinline__ uint4 chunk_add(const uint4& a,
 #ifndef MRFP_RR_HOLD
 #define MRFP_RR_HOLD 1         // k steps (of the 6 per filter row) of the row-reuse kernels multiplied after the next fill has been issued
 #endif
+// 16-bit chunk with the elements whose mask bit is clear set to +0 (bit u of `bits` = element u of the chunk)
+__device__ __forceinline__ uint4 gate_chunk16(const uint4& v, unsigned bits) {
+    auto w = [&](unsigned word, int u) {
+        const unsigned keep = (((bits >> u) & 1u) ? 0x0000ffffu : 0u) | (((bits >> (u + 1)) & 1u) ? 0xffff0000u : 0u);
+        return word & keep;
+    };
+    return make_uint4(w(v.x, 0), w(v.y, 2), w(v.z, 4), w(v.w, 6));
+}
+
 #ifndef MRFP_EARLY_FULL
 #define MRFP_EARLY_FULL 1
 #endif
@@ -795,6 +807,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || RR ? 2 : 3)) void co
                             for (int u = 0; u < 8; ++u)
                                 if (n + u < p.N) chunk_set<T>(av, u, ad[u]);
                         }
+                        if (p.addend_mask) av = gate_chunk16(av, p.addend_mask[((size_t)m * p.ldy + n) >> 3]);
                         v = chunk_add<T>(v, av);
                     }
                     if (full) {
@@ -920,6 +933,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || RR ? 2 : 3)) void co
 #pragma unroll
                         for (int u = 0; u < EPC; ++u)
                             if (n + u < p.N) chunk_set<T>(av, u, ad[u]);
+                    }
+                    if constexpr (sizeof(T) == 2) {
+                        if (p.addend_mask) av = gate_chunk16(av, p.addend_mask[((size_t)m * p.ldy + n) >> 3]);
                     }
                     v = chunk_add<T>(v, av);
                 }
@@ -1233,6 +1249,7 @@ struct BsP {
     const char* w;       // forward pack [N][K]
     char* y;             // [M][ldy]
     const char* addend;  // [M][ldy] or null
+    const unsigned char* addend_mask;   // 1 bit per addend element or null (ConvP::addend_mask)
     float* colstats;     // [ceil(M/64)][2][ldy] or null
     int M, N, ldy;
     int tiles;           // ceil(M / 64)
@@ -1335,7 +1352,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         else dma_wait<0>();                                               // first / last tiles of the range: fewer behind it
         __builtin_amdgcn_s_barrier();                                     // tile landed everywhere; tile - 1 fully consumed
     };
-    auto fetch_addend = [&](int tile, uint4 (&av)[4]) {
+    auto fetch_addend = [&](int tile, uint4 (&av)[4], unsigned (&am)[4]) {
         // skip-gradient addend: fetched before the multiplies of its tile, consumed one tile later (a load issued in the
         // epilogue would be waited for right there: 58 us against 32 us per dgrad launch).  Compiler-tracked on purpose: an
         // untracked inline-asm load is WRONG here (the compiler may copy the destination registers before the data has
@@ -1345,11 +1362,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
             for (int i = 0; i < 4; ++i) {
                 const int m = tile * 64 + i * 16 + l15;
                 av[i] = bload(ar, (m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB);
+                // the gate bits of these 8 channels (all ones without a mask); a plain tracked load, issued with the addend
+                am[i] = (p.addend_mask && m < p.M && nl < p.N) ? p.addend_mask[((size_t)m * p.ldy + nl) >> 3] : 0xffu;
             }
         }
     };
     // one quarter (16 pixels) of the epilogue of `tile` from accumulator set acc
-    auto epilogue_part = [&](int tile, int i, const f32x4 (&acc)[4][2], const uint4 (&av)[4]) {
+    auto epilogue_part = [&](int tile, int i, const f32x4 (&acc)[4][2], const uint4 (&av)[4], const unsigned (&am)[4]) {
         const int m = tile * 64 + i * 16 + l15;
         const bool ok = m < p.M && nl < p.N;                              // (N % 8 == 0 for this kernel: chunks are whole)
         uint4 v;
@@ -1371,14 +1390,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
                 cq[u] += f[u] * f[u];
             }
         }
-        if constexpr (ADD) v = chunk_add<T>(v, av[i]);
+        if constexpr (ADD) v = chunk_add<T>(v, gate_chunk16(av[i], am[i]));
         const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
         u32x4 dv;
         dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
         __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)off, 0, 0);
     };
     // multiplies of `tile` into acc; when prev >= 0 the epilogue of tile `prev` (accumulators pacc, addend pav) in between
-    auto body = [&](int tile, f32x4 (&acc)[4][2], auto has_prev, const f32x4 (&pacc)[4][2], const uint4 (&pav)[4]) {
+    auto body = [&](int tile, f32x4 (&acc)[4][2], auto has_prev, const f32x4 (&pacc)[4][2], const uint4 (&pav)[4], const unsigned (&pam)[4]) {
         const int prev = tile - 1;
         const char* a = ring + ((tile - t0) % NST) * STAGE;
         constexpr int KS = KB * 2;
@@ -1409,8 +1428,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
                 }
             if constexpr (decltype(has_prev)::value) {
                 // the 4 epilogue quarters of the previous tile, spread over the k steps
-                if constexpr (KS >= 4) { if (ks % (KS / 4) == 0) epilogue_part(prev, ks / (KS / 4), pacc, pav); }
-                else { epilogue_part(prev, 2 * ks, pacc, pav); epilogue_part(prev, 2 * ks + 1, pacc, pav); }
+                if constexpr (KS >= 4) { if (ks % (KS / 4) == 0) epilogue_part(prev, ks / (KS / 4), pacc, pav, pam); }
+                else { epilogue_part(prev, 2 * ks, pacc, pav, pam); epilogue_part(prev, 2 * ks + 1, pacc, pav, pam); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1418,34 +1437,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
 
     f32x4 accA[4][2], accB[4][2];
     uint4 avA[4], avB[4];
+    unsigned amA[4] = {0xffu, 0xffu, 0xffu, 0xffu}, amB[4] = {0xffu, 0xffu, 0xffu, 0xffu};
 #pragma unroll
     for (int i = 0; i < 4; ++i) { avA[i] = make_uint4(0u, 0u, 0u, 0u); avB[i] = make_uint4(0u, 0u, 0u, 0u); }
     // first tile: multiplies only
     wait_tile(t0);
-    fetch_addend(t0, avA);
+    fetch_addend(t0, avA, amA);
     if (t0 + NST - 1 < t1) issue(t0 + NST - 1, (NST - 1) % NST);
-    body(t0, accA, NoPrev{}, accB, avB);
+    body(t0, accA, NoPrev{}, accB, avB, amB);
     int tile = t0 + 1;
     for (; tile + 1 < t1; tile += 2) {
         wait_tile(tile);
-        fetch_addend(tile, avB);
+        fetch_addend(tile, avB, amB);
         if (tile + NST - 1 < t1) issue(tile + NST - 1, (tile - t0 + NST - 1) % NST);
-        body(tile, accB, HasPrev{}, accA, avA);
+        body(tile, accB, HasPrev{}, accA, avA, amA);
         wait_tile(tile + 1);
-        fetch_addend(tile + 1, avA);
+        fetch_addend(tile + 1, avA, amA);
         if (tile + NST < t1) issue(tile + NST, (tile + 1 - t0 + NST - 1) % NST);
-        body(tile + 1, accA, HasPrev{}, accB, avB);
+        body(tile + 1, accA, HasPrev{}, accB, avB, amB);
     }
     if (tile < t1) {                            // an even number of tiles: one more B step, then its own epilogue
         wait_tile(tile);
-        fetch_addend(tile, avB);
+        fetch_addend(tile, avB, amB);
         if (tile + NST - 1 < t1) issue(tile + NST - 1, (tile - t0 + NST - 1) % NST);
-        body(tile, accB, HasPrev{}, accA, avA);
+        body(tile, accB, HasPrev{}, accA, avA, amA);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) epilogue_part(tile, i, accB, avB);
+        for (int i = 0; i < 4; ++i) epilogue_part(tile, i, accB, avB, amB);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) epilogue_part(t1 - 1, i, accA, avA);
+        for (int i = 0; i < 4; ++i) epilogue_part(t1 - 1, i, accA, avA, amA);
     }
     if constexpr (STATS) {
         // ONE statistics row block per workgroup range (all its tiles): the 16 lanes of a quarter hold the same 8 channels
@@ -1505,7 +1525,7 @@ static int launch_bstat(const ConvP& c, hipStream_t st) {
         attr_set = true;
     }
     BsP p;
-    p.x = c.x; p.w = c.w; p.y = c.y; p.addend = c.addend; p.colstats = c.colstats;
+    p.x = c.x; p.w = c.w; p.y = c.y; p.addend = c.addend; p.addend_mask = c.addend_mask; p.colstats = c.colstats;
     p.M = c.M; p.N = c.N; p.ldy = c.ldy;
     p.tiles = (c.M + 63) / 64;
     p.panels = (c.N + 127) / 128;
@@ -1683,8 +1703,10 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
                          int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
                          int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
                          float* colstats, const void* bnx, const void* bny, const float* bnmean, const float* bnA,
-                         const float* bnS, void* stream) {
+                         const float* bnS, void* stream, const void* addend_mask = nullptr) {
     MRFP_CHECK(!addend || aligned16(addend), "conv_fwd: addend must be 16-byte aligned");
+    MRFP_CHECK(!addend_mask || (addend && dtype != MRFP_F32 && (N & 7) == 0 && ldy == N && !bnx),
+               "conv_fwd_gated: a gate mask needs an addend, 16-bit activations, N %% 8 == 0 and a dense output");
     MRFP_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
                "conv_fwd: bad arguments");
     MRFP_CHECK(stride >= 1 && dil >= 1 && sstride >= 1 && ldy >= N, "conv_fwd: bad stride/dilation/pitch");
@@ -1700,6 +1722,7 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
         p.stagger8 = stg;
     }
     p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias; p.addend = (const char*)addend; p.colstats = colstats;
+    p.addend_mask = (const unsigned char*)addend_mask;
     p.bnx = (const char*)bnx; p.bny = (const char*)bny; p.bnmean = bnmean; p.bnA = bnA; p.bnS = bnS;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
@@ -1736,6 +1759,7 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
         p.x = (const char*)x + b0 * img;
         p.y = (char*)y + m0 * ldy * esz;
         p.addend = addend ? (const char*)addend + m0 * ldy * esz : nullptr;
+        p.addend_mask = addend_mask ? (const unsigned char*)addend_mask + ((m0 * ldy) >> 3) : nullptr;
         p.bnx = bnx ? (const char*)bnx + m0 * ldy * esz : nullptr;
         p.bny = bny ? (const char*)bny + m0 * ldy * esz : nullptr;
         p.xbytes = (dbg_drop & 1) ? 0u : (unsigned)(bc * img);
@@ -1767,6 +1791,15 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
                          colstats, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
+int mrfp_conv_fwd_gated(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
+                        int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
+                        int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
+                        const void* addend_mask, void* stream) {
+    MRFP_CHECK(addend && addend_mask, "conv_fwd_gated: addend and its gate mask are required");
+    return conv_fwd_impl(x, wpack, bias, y, dtype, B, H, W, C, N, ldy, R, S, Ho, Wo, stride, pad_h, pad_w, dil, sstride, addend,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream, addend_mask);
+}
+
 int mrfp_conv_dgrad_bnstats_ok(int dtype, int64_t C, int64_t N) {
     const int esz = dtype == MRFP_F32 ? 4 : 2;
     return (C * esz) % 128 == 0 && (N * esz) % 16 == 0;
@@ -1792,7 +1825,7 @@ int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
     p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
     p.bnx = bn_bwd ? "" : nullptr;      // (only tested against null by the kernel choice)
-    p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr;
+    p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
     return stats_row_blocks(p, esz);
 }
 /* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */

@@ -175,6 +175,7 @@ def _affine_bwd(dy, x, y, P, Q, R, per_image, plan, want_dres, like, fA=None, fS
 # BatchNorm (+ nearest resize in front) (+ residual) (+ ReLU)
 # ------------------------------------------------------------------------------------------
 SIGN_MASK = [os.environ.get("MRFP_SIGN_MASK", "1") != "0"]     # residual BatchNorm+ReLU: 1-bit sign mask instead of y in backward
+GATED_SKIP = [os.environ.get("MRFP_GATED_SKIP", "1") != "0"]   # ... and the skip gradient gated by the consuming dgrad epilogue
 
 
 class _BatchNormAct(torch.autograd.Function):
@@ -215,6 +216,10 @@ class _BatchNormAct(torch.autograd.Function):
         keep_y = relu and res is not None
         ctx.remask = relu and res is None
         ctx.ymask = bool(keep_y and plan is None and SIGN_MASK[0] and x.element_size() == 2 and C % 8 == 0)
+        # res is the skip alias of a convolution (conv.conv2d(..., want_skip=True)): its gradient is consumed by that
+        # convolution's dgrad epilogue only, which can apply the gate itself -- backward then hands it the incoming
+        # gradient as it is, with the mask attached, instead of writing dy * [y > 0]
+        ctx.gate_skip = bool(ctx.ymask and GATED_SKIP[0] and getattr(res, "_mrfp_skip_alias", False))
         if ctx.ymask:
             y = empty_cl(B, C, Ho, Wo, x.dtype, dev)
             mask = torch.empty(B * Ho * Wo * C // 8, dtype=torch.uint8, device=dev)
@@ -271,9 +276,15 @@ class _BatchNormAct(torch.autograd.Function):
             R.zero_()
         if ctx.ymask:
             dx = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
-            dres = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
-            call("mrfp_affine_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(dx), ptr(dres), dt(dy), B, Ho, Wo, C, ptr(P), ptr(Q), ptr(R), 0,
-                 stream())
+            if ctx.gate_skip and ctx.needs_input_grad[5]:
+                dres = dy.view_as(dy)                  # unmasked; the consumer applies the mask (conv._Conv2d.backward / conv.ungate)
+                dres._mrfp_gate = (y, dres._version)
+                call("mrfp_affine_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(dx), None, dt(dy), B, Ho, Wo, C, ptr(P), ptr(Q), ptr(R), 0,
+                     stream())
+            else:
+                dres = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
+                call("mrfp_affine_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(dx), ptr(dres), dt(dy), B, Ho, Wo, C, ptr(P), ptr(Q), ptr(R),
+                     0, stream())
         else:
             dx, dres = _affine_bwd(dy, x, y, P, Q, R, False, plan, ctx.has_res, x, fA, fS)
         if sw is not None:

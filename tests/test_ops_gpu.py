@@ -432,3 +432,44 @@ def test_residual_bn_relu_sign_mask_equals_reading_y(dtype, shape):
     for a, b_ in zip(*outs):
         assert torch.equal(a, b_)
     assert (outs[0][0] == 0).any() and (outs[0][0] > 0).any()
+
+
+def test_gated_skip_gradient_equals_the_materialised_one():
+    """Residual blocks (reference Resnet.py:202-225): the gradient of the skip connection is dy * [out > 0].  With the sign mask
+    of the block's tail and a skip that is the alias of the block's first convolution, backward hands that convolution the
+    UNMASKED dy + the mask and its dgrad epilogue gates the addend (mrfp_conv_fwd_gated) -- every parameter gradient of a
+    ResNet-50 trunk must be bit-identical with the path that writes the masked gradient, and the gated launches must be the
+    blocks without a downsample branch (12 of 16)."""
+    from mrfp_amd import conv
+    from mrfp_amd.config import cfg
+    from mrfp_amd.network import Resnet
+    o = ops()
+    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.bfloat16
+    try:
+        torch.manual_seed(3)
+        net = Resnet.resnet50(pretrained=False, wt_layer=[0] * 7).to(DEV).train()
+        x = (torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(4)) * 255).to(DEV)
+        grads = []
+        for gated in (True, False):
+            o.GATED_SKIP[0] = gated
+            conv.GATED_SKIP_HITS[0] = 0
+            net.zero_grad(set_to_none=True)
+            y = net(x)
+            y = y[0] if isinstance(y, (tuple, list)) else y
+            y.float().pow(2).mean().backward()
+            torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+            assert conv.GATED_SKIP_HITS[0] == (12 if gated else 0)
+        assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+        for k in grads[0]:
+            assert torch.equal(grads[0][k], grads[1][k]), k
+        # the stand-alone form of the gate (what a consumer that cannot fuse it gets)
+        t = torch.randn(2, 64, 5, 7, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        bits = torch.randint(0, 256, (t.numel() // 8,), dtype=torch.uint8, device=DEV)
+        t._mrfp_gate = (bits, t._version)
+        ref = t.permute(0, 2, 3, 1).reshape(-1, 8).float() * torch.stack([(bits >> i) & 1 for i in range(8)], 1).float()
+        out = conv.ungate(t).permute(0, 2, 3, 1).reshape(-1, 8).float()
+        assert torch.equal(out, ref)
+    finally:
+        o.GATED_SKIP[0] = True
+        cfg.MODEL.ACT_DTYPE = torch.float32
