@@ -257,8 +257,8 @@ def conv_roofline(model, trainer, x, y, args):
     st = torch.cuda.current_stream().cuda_stream
 
     def spy(name, *a):
-        if name in ("mrfp_conv_fwd", "mrfp_conv_wgrad", "mrfp_conv_dgrad_bnstats"):
-            if name == "mrfp_conv_fwd":
+        if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad", "mrfp_conv_dgrad_bnstats"):
+            if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated"):      # (the gated form: same leading arguments)
                 B, H, W, C, N, ldy, R, S, Ho, Wo = a[5:15]
                 f = 2.0 * B * Ho * Wo * N * R * S * C / float(a[19] * a[19])
             elif name == "mrfp_conv_dgrad_bnstats":      # dgrad launch that also produces BatchNorm-backward statistics
@@ -273,7 +273,8 @@ def conv_roofline(model, trainer, x, y, args):
             timer.record(e1, st)
             events.append((e0, e1))
             flops.append(f)
-            shapes.append((name, [int(v) for v in (a[4:17] if name == "mrfp_conv_dgrad_bnstats" else a[5:20])]))
+            shapes.append(("mrfp_conv_fwd" if name == "mrfp_conv_fwd_gated" else name,
+                           [int(v) for v in (a[4:17] if name == "mrfp_conv_dgrad_bnstats" else a[5:20])]))
             return r
         return orig(name, *a)
     conv_mod.call = spy
