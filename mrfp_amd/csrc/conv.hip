@@ -291,7 +291,7 @@ __device__ __forceinline__ uint4 gate_chunk16(const uint4& v, unsigned bits) {
 #define MRFP_EARLY_FULL 1
 #endif
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int NBUF, int TM, int TN, bool DMA, bool BNB = false, bool RR = false>
-__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || RR ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 8 || (RR && TM * TN >= 6) ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     const bool g_stagger8 = p.stagger8 != 0;
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
@@ -1205,7 +1205,7 @@ static int rr_tile(const ConvP& p, int esz) {
         const char* e = getenv("MRFP_CONV_RR");
         g_rr = e ? atoi(e) : 2;
     }
-    if (!g_rr || esz != 2 || p.N <= 64 || p.bnx || use_big_tile(p, esz)) return 0;
+    if (!g_rr || esz != 2 || p.bnx || (p.N > 64 && use_big_tile(p, esz))) return 0;
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.sstride != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
     if (p.dil < 1 || p.dil > 2 || p.pad_h != p.dil || p.pad_w != p.dil) return 0;
     if ((p.cpr & 7) != 0 || (p.W & 15) != 0) return 0;
@@ -1218,6 +1218,15 @@ static int rr_tile(const ConvP& p, int esz) {
     // per tile to amortise the 76 KB prologue), at least one full round of tiles at two workgroups per CU, and an N that does not
     // waste most of its last 128-column tile.  Lost: M = 36 864, 256 -> 256 (384 tiles: 825 vs 880 TFLOP/s against the 96x128
     // tile), C = 128 (862 vs 912), N = 304 (918 vs 977).  Mode 3 lifts these restrictions (A/B runs).
+    if (p.N <= 64) {
+        // 192 x 64 tile (4 waves x 96 x 32) for the N <= 64 layers (C = 64 / 128: 9-18 K tiles of the 256 x 64 tile become 3-6
+        // patch fills).  Measured and OFF (MRFP_CONV_RR64=1 enables it): 544 vs 490 us at 16x128x384^2 -> 64, 77.7 vs 67.9 us at
+        // 16x64x192^2 -> 64 -- the 96 x 32 wave tile reads a third more fragments per MFMA than the plain kernel's 64 x 64, and
+        // two to six fills per tile do not amortise the patch prologue.
+        static int rr64 = -1;
+        if (rr64 < 0) { const char* e = getenv("MRFP_CONV_RR64"); rr64 = e ? atoi(e) : 0; }
+        return (rr64 && g_rr >= 2 && p.N > 32 && fits(192) && p.M / 192 >= 768) ? 19264 : 0;
+    }
     const int64_t t192 = (int64_t)(p.M / 192) * ((p.N + 127) / 128);
     const bool pays = p.C >= 256 && t192 >= 512 && ((p.N + 127) / 128) * 128 - p.N <= 64;
     if (fits(192) && (g_rr >= 3 || (pays && (g_rr >= 2 || use_tile192(p, esz))))) return 192;
@@ -1559,7 +1568,7 @@ static int run_bstat(const ConvP& p, hipStream_t st) {
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
 static int64_t stats_row_blocks(const ConvP& p, int esz) {
     if (use_bstat(p, esz, false)) return (int64_t)bstat_chunks(p.M, p.N);               // conv1x1_bstat_kernel: one per workgroup range
-    if (const int rr = rr_tile(p, esz)) return rr == 192 ? (int64_t)(p.M / 192) * 2 : (int64_t)(p.M / 96);   // row-reuse variants of the two tiles below
+    if (const int rr = rr_tile(p, esz)) return rr == 96 ? (int64_t)(p.M / 96) : (int64_t)(p.M / 192) * 2;   // row-reuse kernels: 96-row (1 wave row) or 192-row tiles
     if (p.N > 64 && use_tile192(p, esz)) return (int64_t)((p.M + 191) / 192) * 2;      // <2,2,3,2>: 192-row tile, 2 wave rows
     if (p.N <= 64) return (int64_t)((p.M + 255) / 256) * 4;          // <4,1,2,2>: 256-row tile, 4 wave rows
     if (use_big_tile(p, esz)) return (int64_t)((p.M + 255) / 256) * 2;  // <2,4,4,2>: 256-row tile, 2 wave rows
@@ -1572,10 +1581,11 @@ static int run_igemm(const ConvP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (use_bstat(p, 2, p.bias != nullptr)) return run_bstat<T>(p, st);
     }
-    if (p.N <= 64) return pick_igemm<T, 4, 1, 2, 2>(p, st);
     if constexpr (sizeof(T) == 2) {
-        if (const int rr = rr_tile(p, 2)) return rr == 192 ? launch_igemm_rr<T, 2, 2, 3, 2>(p, st) : launch_igemm_rr<T, 1, 4, 3, 1>(p, st);
+        if (const int rr = rr_tile(p, 2))
+            return rr == 192 ? launch_igemm_rr<T, 2, 2, 3, 2>(p, st) : rr == 96 ? launch_igemm_rr<T, 1, 4, 3, 1>(p, st) : launch_igemm_rr<T, 2, 2, 3, 1>(p, st);
     }
+    if (p.N <= 64) return pick_igemm<T, 4, 1, 2, 2>(p, st);
     // 256x256 tile (8 waves x 128x64, LDS-DMA, one workgroup per CU).  Measured per shape on MI355X inside the
     // bench workload (bench.py --dump-convs): +8..10 % on long-K 3x3 layers with >= 2 full rounds of tiles
     // (998 vs 913 TF/s at 16x192x192x256->256), but -25 % with ~1 round (M = 36 864), -20 % on short-K 1x1

@@ -244,7 +244,7 @@ def test_row_reuse_kernels_in_subprocess():
         "import torch, torch.nn.functional as F\n"
         "from mrfp_amd import conv\n"
         "for (B,Cin,H,W,Cout,pad) in [(2,128,192,192,256,1),(2,64,96,96,128,1),(3,256,48,48,256,1),(2,128,48,48,128,2),(1,64,384,384,128,1),"
-        "(2,64,192,384,192,1),(4,64,48,16,128,1),(2,192,96,192,320,1),(1,64,24,32,128,2)]:\n"
+        "(2,64,192,384,192,1),(4,64,48,16,128,1),(2,192,96,192,320,1),(1,64,24,32,128,2),(8,64,192,192,64,1),(8,128,96,384,64,1),(16,64,96,96,48,2)]:\n"
         "    g = torch.Generator().manual_seed(1)\n"
         "    x = torch.randn(B,Cin,H,W,generator=g).bfloat16().float(); w = (torch.randn(Cout,Cin,3,3,generator=g)*0.05).bfloat16().float()\n"
         "    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)\n"
@@ -260,6 +260,6 @@ def test_row_reuse_kernels_in_subprocess():
         "    assert all(torch.equal(ys[0], y) for y in ys[1:]), (B,Cin,H,W,Cout,pad)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="4")
+    env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="4", MRFP_CONV_RR64="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
