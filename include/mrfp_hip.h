@@ -157,6 +157,13 @@ int mrfp_bilinear_fwd(const void* x, const void* addend, void* y, int dtype,
 int mrfp_bilinear_bwd(const void* dy, void* dx, int dtype,
                       int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo, int64_t C, int64_t ld_in,
                       void* stream);
+/* The same with the output (forward) / the incoming gradient (backward) being a block of C channels inside a wider NHWC tensor
+ * with ld_out / ld_dy channels per pixel (y / dy point at the block's first channel): Upsample() writing straight into its
+ * slot of a torch.cat(dim=1) buffer and reading its slice of that buffer's gradient (reference deepv3.py:349-353). */
+int mrfp_bilinear_fwd_into(const void* x, void* y, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
+                           int64_t C, int64_t ld_in, int64_t ld_out, void* stream);
+int mrfp_bilinear_bwd_from(const void* dy, void* dx, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
+                           int64_t C, int64_t ld_in, int64_t ld_dy, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MaxPool2d(kernel 3, stride 2, padding 1) (reference Resnet.py:551, deepv3.py:315).

@@ -26,7 +26,7 @@ __device__ __forceinline__ Tap ac_tap(float scale, int dst, int in) {
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(const T* __restrict__ x, const T* __restrict__ addend,
                                                                 T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo,
-                                                                int C, int ldi, int ly) {
+                                                                int C, int ldi, int ly, int ldo) {
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
     const Lanes L = make_lanes(C, VEC);
     const int t = threadIdx.x;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(const T* __restr
             const Tap th = ac_tap(sh, oh, Hi);
             const T* r0 = x + ((size_t)b * Hi + th.i0) * Wi * ldi + (size_t)cv * VEC;
             const T* r1 = x + ((size_t)b * Hi + th.i1) * Wi * ldi + (size_t)cv * VEC;
-            const size_t dl = ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
+            const size_t dl = ((size_t)b * Ho + oh) * Wo * ldo + (size_t)cv * VEC;     // (ldo = C unless y is a channel block of a wider tensor)
             // 4 output pixels per trip, all 16-20 loads issued before the first use
             for (int ow0 = trow; ow0 < Wo; ow0 += 4 * L.rowthreads) {
                 Tap tw[4];
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(const T* __restr
                     rb[u] = load_raw<T, VEC>(r0 + (size_t)tw[u].i1 * ldi);
                     rc[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i0 * ldi);
                     rd[u] = load_raw<T, VEC>(r1 + (size_t)tw[u].i1 * ldi);
-                    if (addend) re[u] = load_raw<T, VEC>(addend + dl + (size_t)ow * C);
+                    if (addend) re[u] = load_raw<T, VEC>(addend + dl + (size_t)ow * ldo);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(const T* __restr
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) o[i] += e[i];
                     }
-                    store_f<T, VEC>(y + dl + (size_t)ow * C, o);
+                    store_f<T, VEC>(y + dl + (size_t)ow * ldo, o);
                 }
             }
         }
@@ -100,7 +100,7 @@ __device__ __forceinline__ void ac_range(int in, int out, int src, int& lo, int&
 // destination row are issued together; the accumulation order (rows outer, columns inner) is the same in both forms.
 template <typename T, int VEC, int KW>
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
-                                                                int Hi, int Wi, int Ho, int Wo, int C, int ldi, int ly) {
+                                                                int Hi, int Wi, int Ho, int Wo, int C, int ldi, int ly, int ldd) {
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
     const Lanes L = make_lanes(C, VEC);
     const int t = threadIdx.x;
@@ -124,12 +124,12 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restr
                     for (int oh = oh0; oh <= oh1; ++oh) {
                         const float wh = ac_weight(sh, oh, Hi, ih);
                         if (wh == 0.f) continue;
-                        const T* dl = dy + ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
+                        const T* dl = dy + ((size_t)b * Ho + oh) * Wo * ldd + (size_t)cv * VEC;
                         // unconditional loads from clamped (always valid) columns: no branch sits between them, so
                         // all KW are in flight together; slots past the range carry weight 0 and are not added
                         VecT<T, VEC> r[KW > 0 ? KW : 1];
 #pragma unroll
-                        for (int k = 0; k < KW; ++k) r[k] = load_raw<T, VEC>(dl + (size_t)min(ow0 + k, ow1) * C);
+                        for (int k = 0; k < KW; ++k) r[k] = load_raw<T, VEC>(dl + (size_t)min(ow0 + k, ow1) * ldd);
 #pragma unroll
                         for (int k = 0; k < KW; ++k) {
                             const float w = wh * ww[k];
@@ -143,12 +143,12 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restr
                     for (int oh = oh0; oh <= oh1; ++oh) {
                         const float wh = ac_weight(sh, oh, Hi, ih);
                         if (wh == 0.f) continue;
-                        const T* dl = dy + ((size_t)b * Ho + oh) * Wo * C + (size_t)cv * VEC;
+                        const T* dl = dy + ((size_t)b * Ho + oh) * Wo * ldd + (size_t)cv * VEC;
                         for (int ow = ow0; ow <= ow1; ++ow) {
                             const float w = wh * ac_weight(sw, ow, Wi, iw);
                             if (w == 0.f) continue;
                             float dv[VEC];
-                            load_f<T, VEC>(dl + (size_t)ow * C, dv);
+                            load_f<T, VEC>(dl + (size_t)ow * ldd, dv);
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) acc[i] += w * dv[i];
                         }
@@ -265,18 +265,21 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
 
 template <typename T>
 static int do_bilinear_fwd(const void* x, const void* addend, void* y, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho,
-                           int64_t Wo, int64_t C, int64_t ldi, hipStream_t st) {
+                           int64_t Wo, int64_t C, int64_t ldi, hipStream_t st, int64_t ldo = 0) {
     const int ly = lines_per_image(B, Ho);
-    const bool ok = aligned16(x) && aligned16(y) && (!addend || aligned16(addend)) && ldi % FullVec<T>::value == 0;
+    if (ldo <= 0) ldo = C;
+    const bool ok = aligned16(x) && aligned16(y) && (!addend || aligned16(addend)) && ldi % FullVec<T>::value == 0 &&
+                    ldo % FullVec<T>::value == 0;
     DISPATCH_VEC(T, C, ok, bilinear_fwd_kernel, dim3((unsigned)(B * ly)), st, (const T*)x, (const T*)addend, (T*)y,
-                 (int)B, (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly);
+                 (int)B, (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly, (int)ldo);
     return 0;
 }
 template <typename T>
 static int do_bilinear_bwd(const void* dy, void* dx, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
-                           int64_t C, int64_t ldi, hipStream_t st) {
+                           int64_t C, int64_t ldi, hipStream_t st, int64_t ldd = 0) {
     const int ly = lines_per_image(B, Hi);
-    const bool ok = aligned16(dy) && aligned16(dx) && ldi % FullVec<T>::value == 0;
+    if (ldd <= 0) ldd = C;
+    const bool ok = aligned16(dy) && aligned16(dx) && ldi % FullVec<T>::value == 0 && ldd % FullVec<T>::value == 0;
     // destination columns per source column: ceil(2*(Wo-1)/(Wi-1)) + 2 (see ac_range)
     const int64_t kw = (Wi > 1 && Wo > 1) ? (2 * (Wo - 1) + (Wi - 1) - 1) / (Wi - 1) + 2 : (int64_t)1 << 30;
     const dim3 grid((unsigned)(B * ly));
@@ -284,7 +287,7 @@ static int do_bilinear_bwd(const void* dy, void* dx, int64_t B, int64_t Hi, int6
     const bool vec = ok && pick_vec<T>(C) > 1;
 #define MRFP_BWD_LAUNCH(VECV, KWV)                                                                                     \
     hipLaunchKernelGGL((bilinear_bwd_kernel<T, VECV, KWV>), grid, dim3(kThreads), 0, st, (const T*)dy, (T*)dx, (int)B, \
-                       (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly)
+                       (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly, (int)ldd)
     if (vec) {
         if (kw <= 4) MRFP_BWD_LAUNCH(full, 4);
         else if (kw <= 8) MRFP_BWD_LAUNCH(full, 8);
@@ -342,6 +345,25 @@ int mrfp_bilinear_bwd(const void* dy, void* dx, int dtype, int64_t B, int64_t Hi
     if (dtype == MRFP_BF16) return do_bilinear_bwd<bf16>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
     if (dtype == MRFP_F16) return do_bilinear_bwd<f16>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream);
     MRFP_CHECK(false, "bilinear_bwd: unknown dtype %d", dtype);
+}
+/* The same with the OUTPUT (forward) / the incoming gradient (backward) being a block of C channels inside a wider NHWC tensor
+ * of ld_out channels per pixel (y / dy point at the block's first channel): Upsample() writing straight into its slot of a
+ * torch.cat(dim=1) buffer and reading its slice of that buffer's gradient (reference deepv3.py:349-353), no copy either way. */
+int mrfp_bilinear_fwd_into(const void* x, void* y, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
+                           int64_t C, int64_t ld_in, int64_t ld_out, void* stream) {
+    MRFP_CHECK(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && ld_in >= C && ld_out >= C, "bilinear_fwd_into: bad arguments");
+    if (dtype == MRFP_F32) return do_bilinear_fwd<float>(x, nullptr, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream, ld_out);
+    if (dtype == MRFP_BF16) return do_bilinear_fwd<bf16>(x, nullptr, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream, ld_out);
+    if (dtype == MRFP_F16) return do_bilinear_fwd<f16>(x, nullptr, y, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream, ld_out);
+    MRFP_CHECK(false, "bilinear_fwd_into: unknown dtype %d", dtype);
+}
+int mrfp_bilinear_bwd_from(const void* dy, void* dx, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo,
+                           int64_t C, int64_t ld_in, int64_t ld_dy, void* stream) {
+    MRFP_CHECK(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && ld_in >= C && ld_dy >= C, "bilinear_bwd_from: bad arguments");
+    if (dtype == MRFP_F32) return do_bilinear_bwd<float>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream, ld_dy);
+    if (dtype == MRFP_BF16) return do_bilinear_bwd<bf16>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream, ld_dy);
+    if (dtype == MRFP_F16) return do_bilinear_bwd<f16>(dy, dx, B, Hi, Wi, Ho, Wo, C, ld_in, (hipStream_t)stream, ld_dy);
+    MRFP_CHECK(false, "bilinear_bwd_from: unknown dtype %d", dtype);
 }
 int mrfp_maxpool_fwd(const void* x, void* y, uint8_t* idx, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
                      void* stream) {

@@ -377,8 +377,7 @@ class MRFPPlus(_DeepLabBase):
         t = self.aspp(t)
         self._tap("aspp", t)
         dec0_up = self.bot_aspp(t)
-        dec0_up = Upsample(dec0_up, low_level.shape[2:])
-        dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))
+        dec1 = self._final1(ops.concat_upsample(dec0_fine, dec0_up, low_level.shape[2:]))     # cat([dec0_fine, Upsample(dec0_up)], 1)
         self._tap("dec1", dec1)
         if o2:                                         # "+" of MRFP+: deepv3.py:355-357
             if cfg.MODEL.COMMUTE_O2:
@@ -411,6 +410,5 @@ class simpleDeepV3Plus(_DeepLabBase):
         x_tuple = self.layer4(self.layer3(self.layer2(x_tuple)))
         dec0_up = self.bot_aspp(self.aspp(x_tuple[0]))
         dec0_fine = self.bot_fine(low_level)
-        dec0_up = Upsample(dec0_up, low_level.shape[2:])
-        dec1 = self._final1(ops.concat_channels([dec0_fine, dec0_up]))
+        dec1 = self._final1(ops.concat_upsample(dec0_fine, dec0_up, low_level.shape[2:]))      # cat([dec0_fine, Upsample(dec0_up)], 1)
         return self._head(dec1, (h, w), gts, training)

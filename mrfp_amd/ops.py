@@ -757,6 +757,50 @@ class _ConcatChannels(torch.autograd.Function):
         return tuple(out)
 
 
+class _ConcatUpsample(torch.autograd.Function):
+    """torch.cat([a, Upsample(b, size)], 1) (the decoder input, reference deepv3.py:349-353) with the bilinear kernel writing
+    straight into the concatenation buffer and, backward, reading its channel block of the buffer's gradient: the 256-channel
+    upsampled map (302 MB at 16 x 192 x 192) is never copied in either direction."""
+
+    @staticmethod
+    def forward(ctx, a, b, Ho, Wo):
+        a, b = _chk(a), _chk(b)
+        B, Ca, H, W = a.shape
+        _, Cb, Hi, Wi = b.shape
+        if (H, W) != (Ho, Wo) or b.shape[0] != B or a.dtype != b.dtype:
+            raise _lib.MrfpHipError("concat_upsample: shape / dtype mismatch")
+        Ct = Ca + Cb
+        y = empty_cl(B, Ct, H, W, a.dtype, a.device)
+        esz = a.element_size()
+        call("mrfp_copy_channels", ptr(a), ptr(y), dt(a), B * H * W, Ca, Ca, 0, Ct, 0, stream())
+        call("mrfp_bilinear_fwd_into", ptr(b), y.data_ptr() + Ca * esz, dt(b), B, Hi, Wi, Ho, Wo, Cb, Cb, Ct, stream())
+        ctx.dims = (B, Ca, Cb, Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        B, Ca, Cb, Hi, Wi, Ho, Wo = ctx.dims
+        Ct, esz = Ca + Cb, dy.element_size()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = empty_cl(B, Ca, Ho, Wo, dy.dtype, dy.device)
+            call("mrfp_copy_channels", ptr(dy), ptr(da), dt(dy), B * Ho * Wo, Ca, Ct, 0, Ca, 0, stream())
+        if ctx.needs_input_grad[1]:
+            db = empty_cl(B, Cb, Hi, Wi, dy.dtype, dy.device)
+            call("mrfp_bilinear_bwd_from", dy.data_ptr() + Ca * esz, ptr(db), dt(dy), B, Hi, Wi, Ho, Wo, Cb, Cb, Ct, stream())
+        return da, db, None, None
+
+
+def concat_upsample(a, b, size):
+    """concat_channels([a, upsample_bilinear(b, size)]) without materialising the upsampled map on its own.  Needs both
+    channel counts to be whole 16-byte chunks (else the plain composition runs)."""
+    epc = 16 // a.element_size()
+    if a.shape[1] % epc or b.shape[1] % epc or (b.shape[2] == 1 and b.shape[3] == 1):
+        return concat_channels([a, upsample_bilinear(b, size)])
+    return _ConcatUpsample.apply(a, b, int(size[0]), int(size[1]))
+
+
 def concat_channels(tensors):
     """torch.cat(dim=1) of NHWC activations (reference deepv3.py:125, 353): pure data movement, done by
     mrfp_copy_channels (a strided channel-block copy) in both directions."""

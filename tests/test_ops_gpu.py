@@ -473,3 +473,23 @@ def test_gated_skip_gradient_equals_the_materialised_one():
     finally:
         o.GATED_SKIP[0] = True
         cfg.MODEL.ACT_DTYPE = torch.float32
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_concat_upsample_equals_the_composition(dtype):
+    """cat([a, Upsample(b)], 1) with the bilinear kernel writing into / reading from its channel block of the concatenation
+    (mrfp_bilinear_fwd_into / mrfp_bilinear_bwd_from): bit-identical with concat_channels([a, upsample_bilinear(b)])."""
+    o = ops()
+    a = rnd(2, 48, 24, 20, seed=21)
+    b = rnd(2, 256, 6, 5, seed=22)
+    gy = rnd(2, 304, 24, 20, seed=23).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        ad, bd = dev(a, dtype), dev(b, dtype)
+        y = o.concat_upsample(ad, bd, (24, 20)) if fused else o.concat_channels([ad, o.upsample_bilinear(bd, (24, 20))])
+        y.backward(gy)
+        outs.append((y.detach().clone(), ad.grad.clone(), bd.grad.clone()))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    yc = torch.cat([a, F.interpolate(b, size=(24, 20), mode="bilinear", align_corners=True)], 1)
+    assert relerr(outs[0][0], yc) < tol(dtype)
