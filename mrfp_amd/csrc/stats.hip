@@ -181,7 +181,11 @@ struct Red { double s, q; };
 
 // block = (kFC channels) x (kFL partial lanes): few channels per block so that even a 64-channel layer
 // spreads over 8 workgroups, many lanes so that every thread only walks n/kFL partials (all independent loads).
-constexpr int kFC = 8, kFL = 128;      // 1024 threads: 2048 partial rows = 16 per thread = 4 batches of independent loads
+#ifndef MRFP_FC
+#define MRFP_FC 8
+#define MRFP_FL 128
+#endif
+constexpr int kFC = MRFP_FC, kFL = MRFP_FL;      // 1024 threads: 2048 partial rows = 16 per thread = 4 batches of independent loads
 constexpr int kFold = 8;                // lanes folded per thread in the first level of the final sum
 __device__ __forceinline__ Red reduce_partials(const float* ws, int64_t first, int64_t n, int64_t C, int c, bool valid,
                                                double (*sm)[2][kFC]) {
