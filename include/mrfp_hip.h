@@ -226,8 +226,8 @@ int mrfp_pack_weight(const float* w, void* wf, void* wd, int dtype, int64_t N, i
                      int64_t Npad, int64_t Cpad, void* stream);
 /* All packs of a model in one launch (after the optimizer step rewrote the fp32 masters).  jobs: device array of
  *   struct { const float* w; void* wf; void* wd; int32_t N, C, R, S, Npad, Cpad; }   (48 bytes, both packs required)
- * prefix: device int64[njobs + 1], exclusive prefix sum of the jobs' brick counts ceil(Npad/64) * ceil(Cpad/8)
- * (one workgroup packs a 64 x 8 x R x S brick of the weight through LDS); total = prefix[njobs].  Every job must have R*S <= 9. */
+ * prefix: device int64[njobs + 1], exclusive prefix sum of the jobs' brick counts ceil(Npad/64) * ceil(Cpad/bc), bc = 8 (64 for pointwise filters)
+ * (one workgroup packs a brick of 64 output x 8 input channels x R x S -- 64 x 64 for pointwise filters -- through LDS); total = prefix[njobs].  Every job must have R*S <= 9. */
 int mrfp_pack_weights_batched(const void* jobs, const int64_t* prefix, int64_t njobs, int64_t total, int dtype, void* stream);
 int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, int dtype,
                   int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,

@@ -102,7 +102,8 @@ def _batched_repack(todo, tag):
                 _, Cphys, Nphys = key[0], key[1], key[2]
                 rec[i]["w"], rec[i]["wf"], rec[i]["wd"] = w.data_ptr(), pk.wf.data_ptr(), pk.wd.data_ptr()
                 rec[i]["dims"] = (N, C, R, S, Nphys, Cphys)
-                prefix[i + 1] = prefix[i] + ((Nphys + 63) // 64) * ((Cphys + 7) // 8)      # 64 x 8 x R x S bricks
+                bc = 64 if R * S == 1 else 8                                           # input channels per brick (conv.hip)
+                prefix[i + 1] = prefix[i] + ((Nphys + 63) // 64) * ((Cphys + bc - 1) // bc)
             dev = items[0][2].device
             st = {"sig": sig, "jobs": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
                   "prefix": torch.from_numpy(prefix).to(dev), "total": int(prefix[-1]), "n": len(items)}

@@ -1652,7 +1652,7 @@ constexpr int kBrickN = 64, kBrickC = 8, kBrickRSMax = 9;      // filters up to 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs,
                                                                     const int64_t* __restrict__ prefix, int njobs, int64_t total) {
-    __shared__ float brick[kBrickN][kBrickC * kBrickRSMax + 1];
+    __shared__ float brick[kBrickN][kBrickC * kBrickRSMax + 1];      // (>= 64 + 1 columns: the pointwise bricks fit)
     const int64_t wg = blockIdx.x;
     int lo = 0, hi = njobs;                 // largest j with prefix[j] <= wg  (uniform: every lane does the same search)
     while (hi - lo > 1) {
@@ -1661,10 +1661,13 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
     }
     const PackJob jb = jobs[lo];
     const int N = jb.N, C = jb.C, R = jb.R, S = jb.S, Npad = jb.Npad, Cpad = jb.Cpad, RS = R * S;
-    const int ncb = (Cpad + kBrickC - 1) / kBrickC;
+    // input channels per brick: 8 for 3x3 filters, 64 for pointwise ones (the same 64 x 72-float brick either way; with 8
+    // channels a pointwise brick was 2 KB of work behind a 7-step binary search: 240 us for the 124 packs of ResNet-101)
+    const int bc = RS == 1 ? kBrickC * 8 : kBrickC;
+    const int ncb = (Cpad + bc - 1) / bc;
     const int local = (int)(wg - prefix[lo]);
-    const int n0 = (local / ncb) * kBrickN, c0 = (local % ncb) * kBrickC;
-    const int run = kBrickC * RS;           // floats per n in this brick (contiguous in w when c0 + 8 <= C)
+    const int n0 = (local / ncb) * kBrickN, c0 = (local % ncb) * bc;
+    const int run = bc * RS;                // floats per n in this brick (contiguous in w when c0 + bc <= C)
     const int t = threadIdx.x;
     for (int e = t; e < kBrickN * run; e += 256) {
         const int nn = e / run, k = e - nn * run;          // k = cc*RS + rs
@@ -1674,9 +1677,9 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
     __syncthreads();
     T* wf = reinterpret_cast<T*>(jb.wf);
     T* wd = reinterpret_cast<T*>(jb.wd);
-    // forward pack: wf[n][rs][c]  (c fastest over 8 consecutive threads)
+    // forward pack: wf[n][rs][c]  (c fastest over bc consecutive threads)
     for (int e = t; e < kBrickN * run; e += 256) {
-        const int cc = e % kBrickC, rest = e / kBrickC;
+        const int cc = e % bc, rest = e / bc;
         const int rs = rest % RS, nn = rest / RS;
         const int n = n0 + nn, c = c0 + cc;
         if (n < Npad && c < Cpad) wf[((size_t)n * RS + rs) * Cpad + c] = from_f<T>(brick[nn][cc * RS + rs]);
