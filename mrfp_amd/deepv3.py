@@ -310,11 +310,11 @@ class MRFPPlus(_DeepLabBase):
         dec = [(getattr(self, "OCdeclayer%d" % i), getattr(self, "OC%d_decbn" % i)) for i in range(1, 5)]
         return enc + dec
 
-    def Normalization_Perturbation_Plus(self, feat, which="np1"):
-        """reference deepv3.py:268-277."""
+    def Normalization_Perturbation_Plus(self, feat, which="np1", res=None):
+        """reference deepv3.py:268-277 (res: added to the result in the same pass)."""
         B, C = feat.shape[0], feat.shape[1]
         alpha, beta_noise = self.rng.np_noise(which, B, C, feat.device)
-        return ops.np_plus(feat, alpha, beta_noise)
+        return ops.np_plus(feat, alpha, beta_noise, res)
 
     def _hrfp(self, xp, h, w):
         """reference deepv3.py:320-327: conv -> nearest resize -> BN(train stats) -> ReLU, x8.  The resize
@@ -356,11 +356,15 @@ class MRFPPlus(_DeepLabBase):
         self._tap("stem", xp)
         OCout_dec, OCout, xp = self._hrfp(xp, h, w)   # always computed, as the reference does (no RNG inside)
         t = xp
-        if npp:
-            t = self.Normalization_Perturbation_Plus(xp, "np1")
-            self._tap("np1", t)
-        if o1:
-            t = ops.add(OCout, t)
+        if npp and o1 and self._taps is None:
+            # NP+(xp) + OCout in ONE pass (the per-stage taps of the parity tests want the intermediate: they take the two-pass form)
+            t = self.Normalization_Perturbation_Plus(xp, "np1", res=OCout)
+        else:
+            if npp:
+                t = self.Normalization_Perturbation_Plus(xp, "np1")
+                self._tap("np1", t)
+            if o1:
+                t = ops.add(OCout, t)
         t = self._low(t, w_arr)
         if fourier is not None:
             t = fourier.at("layer1", t)

@@ -364,8 +364,9 @@ class _NPPlus(torch.autograd.Function):
     normal draws ([B,C,1,1])."""
 
     @staticmethod
-    def forward(ctx, x, alpha, beta_noise):
+    def forward(ctx, x, alpha, beta_noise, res=None):
         x = _chk(x)
+        res = _chk(res, "res") if res is not None else None
         B, C, H, W = x.shape
         a32 = alpha.detach().float().reshape(B, C).contiguous()
         n32 = beta_noise.detach().float().reshape(B, C).contiguous()
@@ -375,9 +376,10 @@ class _NPPlus(torch.autograd.Function):
         nslab, ws = _stats_fwd(x, None)
         call("mrfp_np_finalize", ptr(ws), B, nslab, H * W, C, ptr(a32), ptr(n32), ptr(mu), ptr(sigma), ptr(A),
              ptr(S), stream())
-        y = _affine_fwd(x, None, A, S, True, False, None)
+        y = _affine_fwd(x, res, A, S, True, False, None)      # (+ res: the HRFP output added in the same pass, deepv3.py:333-334)
         ctx.save_for_backward(a32, n32, mu, sigma)
         ctx.shape = (B, C, H, W)
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -393,11 +395,12 @@ class _NPPlus(torch.autograd.Function):
         dx = empty_cl(B, C, H, W, dy.dtype, dy.device)               # dx = alpha*dy + K
         call("mrfp_affine_fwd", ptr(dy), None, ptr(dx), dt(dy), B, H, W, C, H, W, None, None, ptr(a32), ptr(K), 1, 0,
              stream())
-        return dx, None, None
+        return dx, None, None, (dy if ctx.has_res else None)
 
 
-def np_plus(x, alpha, beta_noise):
-    return _NPPlus.apply(x, alpha, beta_noise)
+def np_plus(x, alpha, beta_noise, res=None):
+    """res: a tensor added to the perturbed features in the same pass (y = NP+(x) + res)."""
+    return _NPPlus.apply(x, alpha, beta_noise, res)
 
 
 # ------------------------------------------------------------------------------------------

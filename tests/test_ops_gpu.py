@@ -152,6 +152,17 @@ def test_np_plus(dtype, shape):
     t = tol(dtype)
     assert relerr(yd, yc) < t
     assert relerr(xd.grad, xc.grad) < 10 * t
+    # with the residual added in the same pass (the HRFP output, reference deepv3.py:333-334): fp32 bit-identical with the two
+    # passes; the 16-bit types round once instead of twice
+    r = rnd(*shape, seed=11)
+    if dtype == torch.bfloat16:
+        r = r.bfloat16().float()
+    xd2, rd = dev(x, dtype), dev(r, dtype)
+    y2 = o.np_plus(xd2, alpha.to(DEV), beta.to(DEV), res=rd)
+    y2.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    two = o.add(rd.detach(), o.np_plus(xd2.detach(), alpha.to(DEV), beta.to(DEV)))
+    assert torch.equal(y2, two) if dtype == torch.float32 else relerr(y2, two) < t
+    assert torch.equal(xd2.grad, xd.grad) and relerr(rd.grad, gy) < (1e-7 if dtype == torch.float32 else t)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
