@@ -1697,8 +1697,17 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
 template <typename T>
 __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int H, int W, int Cpad) {
     const int64_t npix = (int64_t)B * H * W;
+    constexpr int EPC = 16 / (int)sizeof(T);
     for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = pix / ((int64_t)H * W), hw = pix % ((int64_t)H * W);
+        if (Cpad == EPC && C <= EPC) {        // the network input (3 -> one 16-byte chunk per pixel): ONE store instead of Cpad
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int c = 0; c < EPC; ++c)
+                if (c < C) chunk_set<T>(v, c, from_f<T>(x[(b * C + c) * (int64_t)H * W + hw]));
+            *reinterpret_cast<uint4*>(y + pix * Cpad) = v;
+            continue;
+        }
         for (int c = 0; c < Cpad; ++c) {
             const float v = c < C ? x[(b * C + c) * (int64_t)H * W + hw] : 0.f;
             y[pix * Cpad + c] = from_f<T>(v);
