@@ -197,6 +197,12 @@ int mrfp_upsample_ce_fwd(const void* P, int64_t ld, const int64_t* target, int d
 int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const float* loss, const float* gscale,
                          void* dlogits, int64_t Cd, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
                          int64_t C, int64_t ignore_index, void* stream);
+/* The same gradient delivered at the LOW resolution: dP[B,Hi,Wi,ld] = bilinear-backward of d(loss)/d(upsampled scores), in
+ * gather form over the low-resolution pixels (every contributing full-resolution pixel's softmax is recomputed): the
+ * full-resolution gradient is neither written nor read back by mrfp_bilinear_bwd.  Pad channels of dP are zeroed. */
+int mrfp_upsample_ce_bwd_lowres(const void* P, int64_t ld, const int64_t* target, const float* loss, const float* gscale,
+                                void* dP, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int64_t C,
+                                int64_t ignore_index, void* stream);
 
 /* Eval: argmax over classes + 19x19 confusion histogram on the device (reference main.py:898-909,
  * metrics.py:122-126): hist[num_classes*gt + pred] += 1 for gt in [0,num_classes).  hist: int64

@@ -175,6 +175,10 @@ def _affine_bwd(dy, x, y, P, Q, R, per_image, plan, want_dres, like, fA=None, fS
 # BatchNorm (+ nearest resize in front) (+ residual) (+ ReLU)
 # ------------------------------------------------------------------------------------------
 SIGN_MASK = [os.environ.get("MRFP_SIGN_MASK", "1") != "0"]     # residual BatchNorm+ReLU: 1-bit sign mask instead of y in backward
+# fused upsample + CE backward straight at the low resolution (gather form: no 0.6 GB full-resolution gradient).  Measured and
+# OFF: 818 us against 276 + 255 us for the two passes at 16 x 768 x 768 x 19 -- recomputing each pixel's softmax for its four
+# low-resolution neighbours costs more than the bytes it saves (MRFP_CE_BWD_LOWRES=1 enables it; tested either way).
+CE_BWD_LOWRES = [os.environ.get("MRFP_CE_BWD_LOWRES", "0") != "0"]
 GATED_SKIP = [os.environ.get("MRFP_GATED_SKIP", "1") != "0"]   # ... and the skip gradient gated by the consuming dgrad epilogue
 
 
@@ -646,10 +650,17 @@ class _UpsampleCrossEntropy(torch.autograd.Function):
         epc = 16 // P.element_size()
         Cd = (C + epc - 1) // epc * epc
         gs = g.detach().float().reshape(1).contiguous()
+        dP = empty_cl(B, ld, Hi, Wi, P.dtype, P.device)
+        if CE_BWD_LOWRES[0]:
+            # gather form over the low-resolution pixels: the full-resolution gradient (0.6 GB at 16 x 768 x 768) is never formed
+            call("mrfp_upsample_ce_bwd_lowres", ptr(P), ld, ptr(target), ptr(loss), ptr(gs), ptr(dP), dt(P), B, Hi, Wi, H, W, C,
+                 ignore, stream())
+            return dP, None, None, None, None, None
         dlog = empty_cl(B, Cd, H, W, P.dtype, P.device)
         call("mrfp_upsample_ce_bwd", ptr(P), ld, ptr(target), ptr(loss), ptr(gs), ptr(dlog), Cd, dt(P), B, Hi, Wi, H, W, C,
              ignore, stream())
-        dP = empty_cl(B, ld, Hi, Wi, P.dtype, P.device) if ld == Cd else zeros_cl(B, ld, Hi, Wi, P.dtype, P.device)
+        if ld != Cd:
+            dP.zero_()
         call("mrfp_bilinear_bwd", ptr(dlog), ptr(dP), dt(P), B, Hi, Wi, H, W, Cd, ld, stream())
         return dP, None, None, None, None, None
 

@@ -324,6 +324,16 @@ def test_fused_upsample_cross_entropy(dtype, case):
     assert abs(ld.item() - lc.item()) / abs(lc.item()) < (1e-5 if dtype == torch.float32 else 2e-3)
     assert relerr(Pd.grad[:, :C], xc.grad) < (2e-5 if dtype == torch.float32 else 1.5e-2)
     assert float(Pd.grad[:, C:].abs().max()) == 0.0
+    # the gather form of the backward at the low resolution (mrfp_upsample_ce_bwd_lowres, off by default: slower) gives the same
+    # result as the two passes (full-resolution gradient, then the bilinear backward)
+    o.CE_BWD_LOWRES[0] = True
+    try:
+        P2 = P.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        (o.upsample_cross_entropy(P2, y.to(DEV), (H, W), C, 255) * 0.7).backward()
+    finally:
+        o.CE_BWD_LOWRES[0] = False
+    assert relerr(P2.grad[:, :C], xc.grad) < (2e-5 if dtype == torch.float32 else 1.5e-2)
+    assert relerr(Pd.grad, P2.grad) < (1e-5 if dtype == torch.float32 else 1.5e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
