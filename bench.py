@@ -96,10 +96,7 @@ def cpu_baseline(args, seconds):
     sd = synth.synth_state_dict(spec, seed=0)
     B, S = 2, 256
     x, y = synth.synth_batch(B, S, S, seed=1)
-    noise = synth.synth_noise(B, seed=2)
-    if args.trunk == "resnet-101":
-        noise["np1_alpha"] = noise["np1_alpha"].repeat(1, 2, 1, 1)
-        noise["np1_beta"] = noise["np1_beta"].repeat(1, 2, 1, 1)
+    noise = synth.synth_noise(B, seed=2, channels=(64 if args.trunk == "resnet-50" else 128, 256))
     keys = orc.trainable_keys(sd)
     mom, it = {}, [0]
 
@@ -137,8 +134,31 @@ def cpu_baseline(args, seconds):
                       "deliver per_pixel_scaled_value images/sec" % (n, args.trunk, B, S, S, args.size, width, scale)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves.  The reference's
+    own launch is a single `python main.py` (reference main_script.sh:1, main.py:39-52), so nothing upstream supplies a
+    launcher.  Runs BEFORE anything touches the GPU, as a CHILD process (never exec: a process that has initialised
+    HIP must not be replaced), relays the child's output (rank 0 prints the one JSON line) and returns its exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MRFP_BENCH_PORT")
+    if port is None:
+        with socket.socket() as s:                       # a free port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -203,6 +223,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     lossv = float(loss.detach())
+    ranks_seen = 1
+    if use_dist:                      # proof that N ranks met on the data-path communicator: a sum of ones over it
+        ones = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     # roofline of the dominant kernel family (the MFMA implicit-GEMM convolutions): algorithmic FLOPs of all conv
     # launches of one step / their summed device time, measured with hipEvents around each launch of ONE EXTRA step.
@@ -214,6 +239,7 @@ def main():
         ms = 1e3 * elapsed / args.steps
         value = args.batch * world * args.steps / elapsed
         out = {"metric": "train images/sec", "value": round(value, 3), "unit": "images/sec", "n_gpus": world,
+               "ranks_seen": ranks_seen,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "%s DeepLabV3+ + MRFP+ (HRFP+NP+ on, HRFP re-drawn every step%s), %dx%d, "

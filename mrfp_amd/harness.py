@@ -115,10 +115,14 @@ class FlatSGD(FlatArena):
             if t is None or buf is None:
                 continue
             p, o = self.params[t], self.offsets[t]
+            if buf.numel() != p.numel():
+                raise _lib.MrfpHipError("optimizer state %s: momentum_buffer has %d values, the parameter %d"
+                                        % (key, buf.numel(), p.numel()))
             self.flat_m[o:o + p.numel()].copy_(buf.reshape(-1).to(self.flat_m.device, torch.float32))
             n += 1
-        if 0 < n < len(self.params):
-            raise _lib.MrfpHipError("optimizer state covers %d of %d trainable tensors" % (n, len(self.params)))
+        # torch.optim.SGD keeps no state for a parameter that never received a gradient: its momentum stays zero here
+        # (what torch's first step on it would start from, up to the dampening-free first-step copy)
+        self.missing_state = len(self.params) - n if n else 0
         self.has_momentum = n > 0
 
     def step(self, gscale: float = 1.0):
@@ -240,7 +244,10 @@ def sync_replicas(model, arena: Optional[FlatArena] = None, group=None, src: int
     them: without this, replicas would differ for ever because only gradients are averaged).  Also makes the three
     perturbation toggles of MRFPPlus.forward agree across ranks for the whole run: the reference seeds python's
     `random` identically everywhere (main.py:38); here rank `src` draws one seed and every rank gets a private
-    `random.Random(seed)` for the toggles -- no per-step collective, no host synchronisation."""
+    `random.Random(seed)` for the toggles -- no per-step collective, no host synchronisation.
+    The perturbation DRAWS, by contrast, differ per rank (reference deepv3.py:272-275, 291-306: NP+
+    normals and the HRFP re-initialisation come from the torch generators): every torch generator of this process is
+    seeded `base + rank` with one base broadcast from `src`, so N replicas apply N different perturbations."""
     if arena is not None:
         dist.broadcast(arena.flat_p, src, group=group)
     with torch.no_grad():
@@ -257,6 +264,17 @@ def sync_replicas(model, arena: Optional[FlatArena] = None, group=None, src: int
         seed = [random.getrandbits(62) if dist.get_rank(group) == src else 0]
         dist.broadcast_object_list(seed, src, group=group)
         rng.seed_toggles(seed[0])
+    base = [random_base_seed() if dist.get_rank(group) == src else 0]
+    dist.broadcast_object_list(base, src, group=group)
+    torch.manual_seed(base[0] + dist.get_rank(group))          # CPU + every device generator of this process
+    return base[0]
+
+
+def random_base_seed() -> int:
+    """Base of the per-rank torch seeds: MRFP_SEED when set (reproducible runs), else drawn from the OS."""
+    import random
+    v = os.environ.get("MRFP_SEED")
+    return int(v) if v is not None else random.SystemRandom().getrandbits(48)
 
 
 class Trainer:
@@ -399,11 +417,14 @@ def save_checkpoint(path, model, epoch, optimizer=None):
     torch.save(ck, path)
 
 
-def load_checkpoint(path_or_dict, model, strict=True, optimizer=None):
+def load_checkpoint(path_or_dict, model, strict=True, optimizer=None, trust_pickle=False):
     """Loads a reference checkpoint (keys with or without the `module.` prefix) into the HIP model and, when
     `optimizer` (FlatSGD / Trainer) is given and the checkpoint has an 'optimizer' entry, the momentum buffers and the
-    schedule position (reference main.py:884-886 + the 'optimizer' entry of main.py:867)."""
-    ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if isinstance(path_or_dict, str) else path_or_dict
+    schedule position (reference main.py:884-886 + the 'optimizer' entry of main.py:867).  The reference's format
+    ({'epoch', 'state_dict', 'optimizer'} of tensors, numbers, lists and dicts) loads under torch's safe unpickler;
+    `trust_pickle=True` opts into arbitrary pickles for files of known origin only."""
+    ck = (torch.load(path_or_dict, map_location="cpu", weights_only=not trust_pickle)
+          if isinstance(path_or_dict, str) else path_or_dict)
     sd = ck["state_dict"] if "state_dict" in ck else ck
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
     with torch.no_grad():

@@ -108,6 +108,7 @@ def _worker_hardening(rank, world, port, outdir):
     before = arena.flat_p.clone()
     sync_replicas(net, arena)
     toggles = [net.rng.toggles() for _ in range(3)]
+    alpha, beta = net.rng.np_noise("np1", 4, 8, torch.device("cpu"))      # the NP+ normals of reference deepv3.py:274-275
     sync = GradSync(arena, bucket_mb=100 * 4 / (1 << 20))    # buckets: {c.*}, {mid.*}, {a.*}
     assert len(sync.buckets) >= 3
     order = []
@@ -119,7 +120,7 @@ def _worker_hardening(rank, world, port, outdir):
     sync.begin()
     net(x, use_mid=(rank == 0)).backward()
     scale = sync.finish()
-    torch.save({"before": before, "after": arena.flat_p.clone(), "stat": net.stat.clone(), "toggles": toggles,
+    torch.save({"before": before, "after": arena.flat_p.clone(), "stat": net.stat.clone(), "toggles": toggles, "alpha": alpha, "beta": beta,
                 "g": arena.flat_g.clone() * scale, "x": x, "order": order}, os.path.join(outdir, "h%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -139,6 +140,8 @@ def test_replica_sync_fixed_bucket_order_and_missing_gradients(tmp_path):
     assert torch.equal(out[0]["after"], out[1]["after"]) and torch.equal(out[0]["after"], out[0]["before"])
     assert torch.equal(out[1]["stat"], torch.zeros(3))                    # buffers follow rank 0 too
     assert out[0]["toggles"] == out[1]["toggles"]                         # same perturbation branches on every rank
+    # ... but each rank draws its OWN perturbation (torch generators seeded base + rank)
+    assert not torch.equal(out[0]["alpha"], out[1]["alpha"]) and not torch.equal(out[0]["beta"], out[1]["beta"])
     assert out[0]["order"] == out[1]["order"] == sorted(out[0]["order"])  # collectives issued in index order
     sys.path.insert(0, ROOT)
     from mrfp_amd.harness import FlatArena
@@ -183,6 +186,16 @@ def test_flat_sgd_state_dict_is_torch_sgd_layout():
         assert mine["param_groups"][0][key] == tsd["param_groups"][0][key], key
     ref_opt2 = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4)
     ref_opt2.load_state_dict({k: v for k, v in mine.items() if k != "mrfp_iteration"})   # and torch accepts ours
+    # torch keeps no state for a parameter that never got a gradient: such a checkpoint loads with zero momentum there
+    part = {"state": {k: v for k, v in tsd["state"].items() if k >= 2}, "param_groups": tsd["param_groups"]}
+    opt3 = FlatSGD(net)
+    opt3.load_state_dict(part)
+    assert opt3.has_momentum and opt3.missing_state == 2
+    o0, n0 = opt3.offsets[0], opt3.params[0].numel()
+    assert float(opt3.flat_m[o0:o0 + n0].abs().max()) == 0.0 and float(opt3.flat_m.abs().max()) > 0.0
+    bad = {"state": {0: {"momentum_buffer": torch.zeros(5)}}, "param_groups": tsd["param_groups"]}
+    with pytest.raises(Exception):
+        FlatSGD(net).load_state_dict(bad)               # a shape mismatch is still an error
     fresh = FlatSGD(TinyNet())
     assert fresh.state_dict()["state"] == {} and not fresh.has_momentum
     with pytest.raises(Exception):
@@ -194,3 +207,26 @@ def test_poly_lr_and_sgd_rule_host_formula():
     assert poly_lr_factor(0) == 1.0
     assert abs(poly_lr_factor(20000) - 0.5 ** 0.9) < 1e-12         # reference main.py:832-839
     assert poly_lr_factor(40000) == 0.0
+
+
+def test_bench_gpus_flag_builds_a_child_launch(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE) must start N ranks through torch.distributed.run as a CHILD
+    process on the loopback address and hand back its exit code (the GPU end-to-end form is tests/test_ddp_gpu.py)."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None, cwd=None):
+        seen.update(cmd=cmd, env=env, cwd=cwd)
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[-7]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -200,3 +200,23 @@ def test_bench_two_ranks_end_to_end():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["cpu_baseline"] is None
+    assert out["ranks_seen"] == 2
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment (the driver's form of the command): bench.py starts the two
+    ranks as a child torch.distributed.run BEFORE touching the GPU and relays rank 0's single JSON line; `ranks_seen` is an
+    all-reduce of ones over the data-path group."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MRFP_BENCH_SHARE_GPU="1", MRFP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--trunk", "resnet-50", "--size", "128", "--batch", "2", "--dtype", "bf16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 4
+    assert out["value"] > 0 and out["cpu_baseline"] is None
