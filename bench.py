@@ -283,13 +283,10 @@ def conv_roofline(model, trainer, x, y, args):
     st = torch.cuda.current_stream().cuda_stream
 
     def spy(name, *a):
-        if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad", "mrfp_conv_dgrad_bnstats"):
+        if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad"):
             if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated"):      # (the gated form: same leading arguments)
                 B, H, W, C, N, ldy, R, S, Ho, Wo = a[5:15]
                 f = 2.0 * B * Ho * Wo * N * R * S * C / float(a[19] * a[19])
-            elif name == "mrfp_conv_dgrad_bnstats":      # dgrad launch that also produces BatchNorm-backward statistics
-                B, H, W, C, N, R, S, Ho, Wo = a[4:13]
-                f = 2.0 * B * Ho * Wo * N * R * S * C / float(a[16] * a[16])
             else:
                 B, H, W, C, Ct, N, ldn, R, S, Ho, Wo = a[5:16]
                 f = 2.0 * B * Ho * Wo * N * R * S * C
@@ -300,7 +297,7 @@ def conv_roofline(model, trainer, x, y, args):
             events.append((e0, e1))
             flops.append(f)
             shapes.append(("mrfp_conv_fwd" if name == "mrfp_conv_fwd_gated" else name,
-                           [int(v) for v in (a[4:17] if name == "mrfp_conv_dgrad_bnstats" else a[5:20])]))
+                           [int(v) for v in a[5:20]]))
             return r
         return orig(name, *a)
     conv_mod.call = spy

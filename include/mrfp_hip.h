@@ -197,12 +197,6 @@ int mrfp_upsample_ce_fwd(const void* P, int64_t ld, const int64_t* target, int d
 int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const float* loss, const float* gscale,
                          void* dlogits, int64_t Cd, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
                          int64_t C, int64_t ignore_index, void* stream);
-/* The same gradient delivered at the LOW resolution: dP[B,Hi,Wi,ld] = bilinear-backward of d(loss)/d(upsampled scores), in
- * gather form over the low-resolution pixels (every contributing full-resolution pixel's softmax is recomputed): the
- * full-resolution gradient is neither written nor read back by mrfp_bilinear_bwd.  Pad channels of dP are zeroed. */
-int mrfp_upsample_ce_bwd_lowres(const void* P, int64_t ld, const int64_t* target, const float* loss, const float* gscale,
-                                void* dP, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int64_t C,
-                                int64_t ignore_index, void* stream);
 
 /* Eval: argmax over classes + 19x19 confusion histogram on the device (reference main.py:898-909,
  * metrics.py:122-126): hist[num_classes*gt + pred] += 1 for gt in [0,num_classes).  hist: int64
@@ -244,11 +238,9 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
  * BatchNorm statistics pass over the conv output disappears (feed it to mrfp_bn_finalize with B = 1,
  * nslab = nblk, count = B*Ho*Wo). */
 int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho,
-                               int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, int64_t bn_bwd);
-/* takes the geometry arguments of the mrfp_conv_fwd call it describes (bn_bwd = 0), or of the convolution a
- * mrfp_conv_dgrad_bnstats call (bn_bwd = 1, stride = 1, that call's own B, H, W, C, N, ...; see below): the kernel the launch
- * runs on (tile shape, the B-stationary pointwise kernel, the row-reuse 3x3 kernels) -- and with it the number of row blocks --
- * depends on all of them. */
+                               int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride);
+/* takes the geometry arguments of the mrfp_conv_fwd call it describes: the kernel the launch runs on (tile shape, the pointwise
+ * kernels, the row-reuse 3x3 kernels) -- and with it the number of row blocks -- depends on all of them. */
 /* The K-loop gathers through 32-bit buffer-descriptor offsets, so one launch reads at most 3.75 GB of input; a larger
  * activation (BASELINE.json configs[4] at 16 images per GPU: 16 x 256 x 512 x 1024 bf16 = 4.3 GB) is walked in batch ranges
  * by mrfp_conv_fwd / mrfp_conv_wgrad themselves (one image must stay below the limit).  Returns 1 when B images of
@@ -267,20 +259,6 @@ int mrfp_conv_fwd_gated(const void* x, const void* wpack, const float* bias, voi
                         int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,
                         int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil,
                         int64_t sstride, const void* addend, const void* addend_mask, void* stream);
-/* dgrad that feeds a BatchNorm backward (reference: autograd of Norm2d -> ReLU -> nn.Conv2d chains, Resnet.py:202-216):
- * dx[B,Ho,Wo,0:N] = dgrad(dy[B,H,W,C], wd pack) (+ addend) as mrfp_conv_fwd with stride 1 / source stride `sstride`, and in
- * the SAME launch the BatchNorm-backward statistics of dx, which is dL/d(BN output): per row block
- *   bnstats[blk][0][n] = sum g',  bnstats[blk][1][n] = sum g' * (bn_x - bn_mean[n]),   g' = dx * mask,
- *   mask = (bn_y > 0) if bn_y != NULL, else (bn_x*bn_fA[n] + bn_fS[n] > 0) if bn_fA != NULL, else 1
- * (bn_x / bn_y: the BatchNorm's input / output, [B,Ho,Wo,N] dense, same dtype) -- the layout mrfp_stats_bwd produces, so the
- * separate pass over (dy, x) disappears: hand rows [final_first, final_first + final_count) of bnstats (float
- * [mrfp_conv_stats_rows(nblk)][2][N], nblk = mrfp_conv_stats_blocks(dtype, B, H, W, C, N, R, S, Ho, Wo, 1, pad_h, pad_w, dil, sstride, 1) with this call's own arguments) to mrfp_bn_bwd_finalize
- * with B = 1, nslab = final_count.  Needs mrfp_conv_dgrad_bnstats_ok(dtype, C, N) (C*sizeof % 128 == 0, N*sizeof % 16 == 0). */
-int mrfp_conv_dgrad_bnstats_ok(int dtype, int64_t C, int64_t N);
-int mrfp_conv_dgrad_bnstats(const void* dy, const void* wpack, void* dx, int dtype, int64_t B, int64_t H, int64_t W,
-                            int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho, int64_t Wo, int64_t pad_h, int64_t pad_w,
-                            int64_t dil, int64_t sstride, const void* addend, const void* bn_x, const void* bn_y,
-                            const float* bn_mean, const float* bn_fA, const float* bn_fS, float* bnstats, void* stream);
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q);
 int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype,
                     int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,

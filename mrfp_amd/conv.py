@@ -147,16 +147,6 @@ def _out_size(H, R, stride, pad, dil):
     return (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
 
 
-# BatchNorm-backward statistics in the dgrad epilogue of the convolution that consumes the BatchNorm's output
-# (mrfp_conv_dgrad_bnstats).  Built, tested (tests/test_ops_gpu.py) and MEASURED in round 2: it removes the statistics
-# pass (4.5 ms per bench step) but the dgrad launches get slower by the same 3.5 ms -- their epilogue now waits on
-# 16-byte global loads of x (and of y for residual blocks: 2 x 75 MB behind a 1024-channel dgrad), and a convolution's
-# epilogue moves bytes at 1.5-2.5 TB/s where the dedicated pass runs at 5.4 TB/s (profiles/r02_experiments.md).  OFF by
-# default; MRFP_FUSE_BN_BWD=1 enables it.
-FUSE_BN_BWD = [_os.environ.get("MRFP_FUSE_BN_BWD", "0") == "1"]
-FUSED_BN_BWD_HITS = [0, 0]       # [launches that produced statistics, BatchNorm backwards that consumed them]
-
-
 # ---- second stream for the weight gradients ---------------------------------------------------------------------
 USE_WGRAD_STREAM = [_os.environ.get("MRFP_WGRAD_STREAM", "1") != "0"]
 _WGRAD_STREAMS = {}
@@ -225,7 +215,7 @@ class _Conv2d(torch.autograd.Function):
         L = _lib.lib()
         if bias is None and FUSE_STATS[0] and L.mrfp_conv_single_launch(B, H * W * Cphys * x.element_size()):
             # no bias = a convolution that feeds a normalisation layer: let the epilogue produce its statistics
-            nblk = int(L.mrfp_conv_stats_blocks(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1, 0))
+            nblk = int(L.mrfp_conv_stats_blocks(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1))
             stats = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Nphys, dtype=torch.float32, device=x.device)
         call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
              Ho, Wo, stride, pad_h, pad_w, dil, 1, None, ptr(stats), stream())
@@ -236,9 +226,6 @@ class _Conv2d(torch.autograd.Function):
             _LAST_STATS[0] = None
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, pad_h, pad_w, dil, Nphys, Ho, Wo)
-        # x is the output of a BatchNorm (+ReLU) (ops._BatchNormAct tags it): this conv's dgrad launch can produce that
-        # BatchNorm's backward statistics in its epilogue (mrfp_conv_dgrad_bnstats)
-        ctx.bn = getattr(x, "_mrfp_bnctx", None) if FUSE_BN_BWD[0] else None
         ctx.set_materialize_grads(False)
         if want_skip:
             return y, x.view_as(x)
@@ -259,11 +246,6 @@ class _Conv2d(torch.autograd.Function):
                 raise _lib.MrfpHipError("dgrad through a channel-padded input is not supported")
             pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
             dx = empty_cl(B, Cphys, H, W, x.dtype, x.device)
-            bn = ctx.bn
-            L = _lib.lib()
-            use_bnstats = bool(bn is not None and bn["x"].shape == dx.shape and bn["x"].dtype == dx.dtype and
-                               L.mrfp_conv_dgrad_bnstats_ok(dt(dy), Nphys, Cphys) and
-                               L.mrfp_conv_single_launch(B, Ho * Wo * Nphys * dy.element_size()))
             gate = None
             if dskip is not None:
                 g = getattr(dskip, "_mrfp_gate", None)
@@ -271,7 +253,7 @@ class _Conv2d(torch.autograd.Function):
                     # the skip-connection gradient of a residual tail arrives UNMASKED with that tail's sign mask attached
                     # (ops._BatchNormAct.backward): the dgrad epilogue applies the gate while it adds -- dy * [y > 0] is never
                     # written or re-read.  Anything this launch cannot do that way gets the plain gradient.
-                    if (not use_bnstats and g[1] == dskip._version and dskip.dtype == x.dtype and x.element_size() == 2
+                    if (g[1] == dskip._version and dskip.dtype == x.dtype and x.element_size() == 2
                             and Cphys % 8 == 0 and dskip.shape == dx.shape and dskip.is_contiguous(memory_format=CL)):
                         gate = g[0]
                     else:
@@ -279,20 +261,7 @@ class _Conv2d(torch.autograd.Function):
                 dskip = _chk(dskip, "dskip")
                 if dskip.dtype != x.dtype:
                     dskip = dskip.to(x.dtype)
-            if use_bnstats:
-                # dx is dL/d(BatchNorm output): its backward statistics come out of this launch's epilogue
-                nblk = int(L.mrfp_conv_stats_blocks(dt(dy), B, Ho, Wo, Nphys, Cphys, R, S, H, W, 1, dil * (R - 1) - pad_h,
-                                                     dil * (S - 1) - pad_w, dil, stride, 1))
-                st = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Cphys, dtype=torch.float32, device=x.device)
-                call("mrfp_conv_dgrad_bnstats", ptr(dy), ptr(pk.wd), ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, R, S, H, W,
-                     dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), ptr(bn["x"]),
-                     ptr(x if bn["mask_from_y"] else None), ptr(bn["mean"]), ptr(bn["fA"]), ptr(bn["fS"]), ptr(st), stream())
-                first, cnt = int(L.mrfp_conv_stats_final_first(nblk)), int(L.mrfp_conv_stats_final_count(nblk))
-                # (the version check in ops._BatchNormAct.backward rejects the statistics if autograd accumulated another
-                #  gradient into this tensor in place before handing it on)
-                dx._mrfp_bnstats = (st[first * 2 * Cphys:(first + cnt) * 2 * Cphys], cnt, bn["token"], dx._version)
-                FUSED_BN_BWD_HITS[0] += 1
-            elif gate is not None:
+            if gate is not None:
                 call("mrfp_conv_fwd_gated", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
                      1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), ptr(gate), stream())
                 GATED_SKIP_HITS[0] += 1

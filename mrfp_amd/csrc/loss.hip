@@ -301,86 +301,8 @@ __global__ __launch_bounds__(kCeThreads) void upsample_ce_bwd_kernel(const T* __
     }
 }
 
-// Backward in GATHER form over the LOW-resolution pixels: d(loss)/dP[b, ih, iw, :] = sum over the full-resolution pixels whose
-// bilinear footprint contains (ih, iw) of  weight * (softmax - onehot) * k.  The full-resolution gradient [B, C, H, W] (0.6 GB
-// at 16 x 768 x 768 x 32) is never written and never read back by a separate bilinear-backward pass; every contributing pixel's
-// softmax is recomputed from the (L2-resident) low-resolution scores -- about four times the arithmetic of the two-pass
-// form, a fraction of its bytes -- and measured SLOWER (818 us against 276 + 255 us at 16 x 768 x 768 x 19), so the operator
-// layer keeps the two passes by default.  Weights and footprints use the forward's float expressions (up_logits), the range
-// is the exact-integer bound of resize_pool.hip::ac_range.
-__device__ __forceinline__ void up_range(int in, int out, int src, int& lo, int& hi) {
-    if (in <= 1 || out <= 1) { lo = 0; hi = out - 1; return; }
-    const long long a = in - 1, b = out - 1;
-    lo = src >= 1 ? (int)(((long long)(src - 1) * b) / a) : 0;
-    hi = (int)(((long long)(src + 1) * b + a - 1) / a);
-    if (lo < 0) lo = 0;
-    if (hi > out - 1) hi = out - 1;
-}
-__device__ __forceinline__ float up_weight(float scale, int dst, int in, int src) {
-    const float f = scale * (float)dst;
-    const int i0 = (int)f, i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    const float l1 = f - (float)i0, l0 = 1.f - l1;
-    return (i0 == src ? l0 : 0.f) + (i1 == src ? l1 : 0.f);
-}
-
-template <typename T, int CP>
-__global__ __launch_bounds__(kCeThreads) void upsample_ce_bwd_gather_kernel(const T* __restrict__ P, int ld, const int64_t* __restrict__ target,
-                                                                            const float* __restrict__ loss, const float* __restrict__ gscale,
-                                                                            T* __restrict__ dP, int B, int Hi, int Wi, int H, int W, int C,
-                                                                            int64_t ignore) {
-    constexpr int EPC = 16 / (int)sizeof(T);
-    const int64_t nsrc = (int64_t)B * Hi * Wi;
-    const float k = (gscale ? gscale[0] : 1.f) / loss[1];
-    const float sh = up_scale(Hi, H), sw = up_scale(Wi, W);
-    for (int64_t q = (int64_t)blockIdx.x * kCeThreads + threadIdx.x; q < nsrc; q += (int64_t)gridDim.x * kCeThreads) {
-        const int b = (int)(q / ((int64_t)Hi * Wi)), rem = (int)(q - (int64_t)b * Hi * Wi);
-        const int ih = rem / Wi, iw = rem - ih * Wi;
-        int oh0, oh1, ow0, ow1;
-        up_range(Hi, H, ih, oh0, oh1);
-        up_range(Wi, W, iw, ow0, ow1);
-        float acc[CP];
-#pragma unroll
-        for (int c = 0; c < CP; ++c) acc[c] = 0.f;
-        for (int oh = oh0; oh <= oh1; ++oh) {
-            const float wh = up_weight(sh, oh, Hi, ih);
-            if (wh == 0.f) continue;
-            const int64_t* trow = target + ((int64_t)b * H + oh) * W;
-            for (int ow = ow0; ow <= ow1; ++ow) {
-                const float w = wh * up_weight(sw, ow, Wi, iw);
-                if (w == 0.f) continue;
-                const int64_t tg = trow[ow];
-                if (tg == ignore || tg < 0 || tg >= C) continue;
-                float g[CP];
-                up_logits<T, CP>(P, ld, Hi, Wi, H, W, C, b, oh, ow, g);
-                float m = -INFINITY;
-#pragma unroll
-                for (int c = 0; c < CP; ++c) if (c < C) m = fmaxf(m, g[c]);
-                float s = 0.f;
-#pragma unroll
-                for (int c = 0; c < CP; ++c) { g[c] = c < C ? __expf(g[c] - m) : 0.f; s += g[c]; }
-                const float inv = w * k / s, wk = w * k;
-#pragma unroll
-                for (int c = 0; c < CP; ++c) acc[c] += c < C ? g[c] * inv - (c == (int)tg ? wk : 0.f) : 0.f;
-            }
-        }
-        T* d = dP + q * ld;
-#pragma unroll
-        for (int c0 = 0; c0 < CP; c0 += EPC) {
-            if (c0 < ld) {
-                float o[EPC];
-#pragma unroll
-                for (int i = 0; i < EPC; ++i) o[i] = acc[c0 + i];
-                store_f<T, EPC>(d + c0, o);
-            }
-        }
-        for (int c0 = CP; c0 < ld; c0 += EPC) {          // pad chunks of the score buffer beyond CP: zero gradient
-            float o[EPC];
-#pragma unroll
-            for (int i = 0; i < EPC; ++i) o[i] = 0.f;
-            store_f<T, EPC>(d + c0, o);
-        }
-    }
-}
+// (A backward in gather form over the LOW-resolution pixels -- the full-resolution gradient never written -- was built and
+// measured in round 2: 818 us against 276 + 255 us for the two passes at 16 x 768 x 768 x 19; removed, profiles/r02_experiments.md.)
 
 // dispatch on CP = C rounded up to 8 (8 .. kMaxClasses)
 struct UpCeArgs {
@@ -389,10 +311,7 @@ struct UpCeArgs {
 };
 template <typename T, int CP>
 static void launch_up_ce(const UpCeArgs& a, bool bwd) {
-    if (bwd && a.Cd < 0)          // gather form: dlogits is the LOW-resolution gradient dP[B, Hi, Wi, ld]
-        hipLaunchKernelGGL((upsample_ce_bwd_gather_kernel<T, CP>), dim3(a.nb), dim3(kCeThreads), 0, a.st, (const T*)a.P, a.ld, a.target,
-                           a.loss, a.gscale, (T*)a.dlogits, a.B, a.Hi, a.Wi, a.H, a.W, a.C, a.ignore);
-    else if (!bwd)
+    if (!bwd)
         hipLaunchKernelGGL((upsample_ce_fwd_kernel<T, CP>), dim3(a.nb), dim3(kCeThreads), 0, a.st, (const T*)a.P, a.ld, a.target,
                            a.B, a.Hi, a.Wi, a.H, a.W, a.C, a.ignore, a.ws);
     else
@@ -451,28 +370,6 @@ int mrfp_upsample_ce_bwd(const void* P, int64_t ld, const int64_t* target, const
     const int nb = mrfp::ce_blocks(B * H * W);
     mrfp::UpCeArgs a{P, (int)ld, target, loss, gscale, dlogits, (int)Cd, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
                      ignore_index, nullptr, nb, st};
-    if (dtype == MRFP_F32) mrfp::dispatch_up_ce<float>(a, true);
-    else if (dtype == MRFP_F16) mrfp::dispatch_up_ce<mrfp::f16>(a, true);
-    else mrfp::dispatch_up_ce<mrfp::bf16>(a, true);
-    MRFP_LAUNCH_CHECK();
-    return 0;
-}
-
-int mrfp_upsample_ce_bwd_lowres(const void* P, int64_t ld, const int64_t* target, const float* loss, const float* gscale,
-                                void* dP, int dtype, int64_t B, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int64_t C,
-                                int64_t ignore_index, void* stream) {
-    MRFP_CHECK(P && target && loss && dP && B > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0 && C > 0 && C <= mrfp::kMaxClasses,
-               "upsample_ce_bwd_lowres: bad arguments");
-    const int esz = dtype == MRFP_F32 ? 4 : 2, epc = 16 / esz;
-    MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16 || dtype == MRFP_F16, "upsample_ce_bwd_lowres: unknown dtype %d", dtype);
-    MRFP_CHECK(ld % epc == 0 && ld >= (C + epc - 1) / epc * epc && mrfp::aligned16(P) && mrfp::aligned16(dP),
-               "upsample_ce_bwd_lowres: the score buffer must be channel-padded to 16-byte chunks (ld=%lld)", (long long)ld);
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t nsrc = B * Hi * Wi;
-    int64_t nb = (nsrc + mrfp::kCeThreads - 1) / mrfp::kCeThreads;      // one low-resolution pixel per thread
-    if (nb > (1 << 20)) nb = 1 << 20;
-    mrfp::UpCeArgs a{P, (int)ld, target, loss, gscale, dP, -1, (int)B, (int)Hi, (int)Wi, (int)H, (int)W, (int)C,
-                     ignore_index, nullptr, (int)nb, st};
     if (dtype == MRFP_F32) mrfp::dispatch_up_ce<float>(a, true);
     else if (dtype == MRFP_F16) mrfp::dispatch_up_ce<mrfp::f16>(a, true);
     else mrfp::dispatch_up_ce<mrfp::bf16>(a, true);

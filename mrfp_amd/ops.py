@@ -175,10 +175,6 @@ def _affine_bwd(dy, x, y, P, Q, R, per_image, plan, want_dres, like, fA=None, fS
 # BatchNorm (+ nearest resize in front) (+ residual) (+ ReLU)
 # ------------------------------------------------------------------------------------------
 SIGN_MASK = [os.environ.get("MRFP_SIGN_MASK", "1") != "0"]     # residual BatchNorm+ReLU: 1-bit sign mask instead of y in backward
-# fused upsample + CE backward straight at the low resolution (gather form: no 0.6 GB full-resolution gradient).  Measured and
-# OFF: 818 us against 276 + 255 us for the two passes at 16 x 768 x 768 x 19 -- recomputing each pixel's softmax for its four
-# low-resolution neighbours costs more than the bytes it saves (MRFP_CE_BWD_LOWRES=1 enables it; tested either way).
-CE_BWD_LOWRES = [os.environ.get("MRFP_CE_BWD_LOWRES", "0") != "0"]
 GATED_SKIP = [os.environ.get("MRFP_GATED_SKIP", "1") != "0"]   # ... and the skip gradient gated by the consuming dgrad epilogue
 
 
@@ -233,16 +229,6 @@ class _BatchNormAct(torch.autograd.Function):
             mask = None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, (mask if ctx.ymask else y) if keep_y else None, w32, mean, invstd, A, S)
-        if plan is None and (x.requires_grad or (weight is not None and weight.requires_grad)):
-            # the convolution that consumes y can produce this layer's backward statistics in its dgrad epilogue
-            # (mrfp_amd/conv.py, mrfp_conv_dgrad_bnstats); the token ties those statistics to THIS layer
-            ctx.token = object()
-            # (no reference to y itself in here: y -> dict -> y would be a cycle that keeps the activation alive until the
-            #  garbage collector runs; the consuming convolution has y anyway -- it is its input)
-            y._mrfp_bnctx = {"x": x, "mask_from_y": keep_y, "mean": mean, "fA": A if ctx.remask else None,
-                             "fS": S if ctx.remask else None, "token": ctx.token}
-        else:
-            ctx.token = None
         return y
 
     @staticmethod
@@ -252,15 +238,7 @@ class _BatchNormAct(torch.autograd.Function):
         plan = ctx.plan
         B, Ho, Wo, C, *_ = _geom(x, plan)
         fA, fS = (A, S) if ctx.remask else (None, None)
-        fused = getattr(dy, "_mrfp_bnstats", None)
-        if fused is not None and ctx.token is not None and fused[2] is ctx.token and fused[3] == dy._version and \
-                fused[0].numel() == fused[1] * 2 * C:
-            # dy came straight out of the dgrad launch of the one convolution that consumes this layer's output, and that
-            # launch already summed dy' and dy'*(x - mean) per row block: no pass over (dy, x) here
-            ws, nb_, nslab = fused[0], 1, fused[1]
-            from . import conv as _conv
-            _conv.FUSED_BN_BWD_HITS[1] += 1
-        elif ctx.ymask:                    # y holds the sign mask
+        if ctx.ymask:                      # y holds the sign mask
             nslab, ws = _stats_ws(B, Ho, C, x.device)
             call("mrfp_stats_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(mean), 0, dt(x), B, Ho, Wo, C, ptr(ws), stream())
             nb_ = B
@@ -651,11 +629,6 @@ class _UpsampleCrossEntropy(torch.autograd.Function):
         Cd = (C + epc - 1) // epc * epc
         gs = g.detach().float().reshape(1).contiguous()
         dP = empty_cl(B, ld, Hi, Wi, P.dtype, P.device)
-        if CE_BWD_LOWRES[0]:
-            # gather form over the low-resolution pixels: the full-resolution gradient (0.6 GB at 16 x 768 x 768) is never formed
-            call("mrfp_upsample_ce_bwd_lowres", ptr(P), ld, ptr(target), ptr(loss), ptr(gs), ptr(dP), dt(P), B, Hi, Wi, H, W, C,
-                 ignore, stream())
-            return dP, None, None, None, None, None
         dlog = empty_cl(B, Cd, H, W, P.dtype, P.device)
         call("mrfp_upsample_ce_bwd", ptr(P), ld, ptr(target), ptr(loss), ptr(gs), ptr(dlog), Cd, dt(P), B, Hi, Wi, H, W, C,
              ignore, stream())

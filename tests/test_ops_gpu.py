@@ -324,16 +324,6 @@ def test_fused_upsample_cross_entropy(dtype, case):
     assert abs(ld.item() - lc.item()) / abs(lc.item()) < (1e-5 if dtype == torch.float32 else 2e-3)
     assert relerr(Pd.grad[:, :C], xc.grad) < (2e-5 if dtype == torch.float32 else 1.5e-2)
     assert float(Pd.grad[:, C:].abs().max()) == 0.0
-    # the gather form of the backward at the low resolution (mrfp_upsample_ce_bwd_lowres, off by default: slower) gives the same
-    # result as the two passes (full-resolution gradient, then the bilinear backward)
-    o.CE_BWD_LOWRES[0] = True
-    try:
-        P2 = P.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-        (o.upsample_cross_entropy(P2, y.to(DEV), (H, W), C, 255) * 0.7).backward()
-    finally:
-        o.CE_BWD_LOWRES[0] = False
-    assert relerr(P2.grad[:, :C], xc.grad) < (2e-5 if dtype == torch.float32 else 1.5e-2)
-    assert relerr(Pd.grad, P2.grad) < (1e-5 if dtype == torch.float32 else 1.5e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -364,17 +354,18 @@ def test_concat_channels(dtype, chans):
     (2, 64, 48, 48, 64, 1, 1, 1, True),         # N = 64 -> the 256x64 tile (no wide epilogue)
     (16, 64, 24, 24, 256, 3, 1, 1, False),      # M = 9216 rows: several row blocks per launch
 ])
-def test_bn_backward_statistics_from_the_dgrad_epilogue(dtype, tol, case):
-    """mrfp_conv_dgrad_bnstats: the convolution that consumes a BatchNorm(+ReLU) output produces that layer's backward
-    statistics (sum dy', sum dy'(x - mean)) in its dgrad epilogue.  Checked against (a) the same chain with the separate
-    statistics pass (MRFP_FUSE_BN_BWD off) and (b) torch autograd on the CPU in fp32."""
+def test_conv_bn_relu_conv_chain_backward_vs_torch(dtype, tol, case):
+    """conv_a -> BatchNorm(+residual) -> ReLU -> conv_b (reference Resnet.py:202-216 and its autograd): every gradient of the
+    chain against torch autograd on the CPU in fp32 -- the BatchNorm-backward statistics pass, the recomputed / sign-mask ReLU
+    gates and the strided / dilated dgrad launches that feed it.  (Round 2 also produced those statistics in the dgrad epilogue,
+    mrfp_conv_dgrad_bnstats; it measured a wash -- profiles/r02_experiments.md -- and was removed in round 3.)"""
     import torch.nn.functional as F
     from mrfp_amd import conv, ops
     B, Cin, H, W, Cm, k, st, dil, with_res = case
     g = torch.Generator().manual_seed(sum(case[:8]))
     x0 = torch.randn(B, Cin, H, W, generator=g)
     wa = torch.randn(Cm, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5
-    wb = torch.randn(64, Cm, k, k, generator=g) * (1.0 / (Cm * k * k)) ** 0.5     # 64 channels: whole 128-byte K tiles in the dgrad
+    wb = torch.randn(64, Cm, k, k, generator=g) * (1.0 / (Cm * k * k)) ** 0.5
     gam, bet = torch.rand(Cm, generator=g) + 0.5, torch.randn(Cm, generator=g) * 0.2
     res = torch.randn(B, Cm, H, W, generator=g) if with_res else None
     if dtype != torch.float32:
@@ -391,9 +382,7 @@ def test_bn_backward_statistics_from_the_dgrad_epilogue(dtype, tol, case):
         y.backward(gy)
         return gy, (x.grad, a.grad, ga.grad, be.grad)
 
-    def hip(gy, fuse):
-        conv.FUSE_BN_BWD[0] = fuse
-        hits = list(conv.FUSED_BN_BWD_HITS)
+    def hip(gy):
         x = x0.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         a, b2 = wa.to(DEV).requires_grad_(True), wb.to(DEV).requires_grad_(True)
         ga, be = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
@@ -401,22 +390,14 @@ def test_bn_backward_statistics_from_the_dgrad_epilogue(dtype, tol, case):
         h = ops.batch_norm_act(conv.conv2d(x, a, None, 1, 0, 1), ga, be, None, None, training=True, relu=True, res=r)
         y = conv.conv2d(h, b2, None, st, pad, dil)
         y.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
-        used = (conv.FUSED_BN_BWD_HITS[0] - hits[0], conv.FUSED_BN_BWD_HITS[1] - hits[1])
-        return (x.grad.float().cpu(), a.grad.cpu(), ga.grad.cpu(), be.grad.cpu()), used
+        return x.grad.float().cpu(), a.grad.cpu(), ga.grad.cpu(), be.grad.cpu()
 
     gy, ref = cpu()
     if dtype != torch.float32:
         gy = gy.to(dtype).float()
-    was = conv.FUSE_BN_BWD[0]
-    try:
-        plain, used0 = hip(gy, False)
-        fused, used1 = hip(gy, True)
-    finally:
-        conv.FUSE_BN_BWD[0] = was
-    assert used0 == (0, 0) and used1 == (1, 1), (used0, used1)        # the fused path really ran, and only when asked
-    for name, f, p_, r_ in zip(("dx", "dw", "dgamma", "dbeta"), fused, plain, ref):
+    got = hip(gy)
+    for name, f, r_ in zip(("dx", "dw", "dgamma", "dbeta"), got, ref):
         scale = r_.abs().max().item()
-        assert (f - p_).abs().max().item() <= 0.05 * tol * scale + 1e-7, name       # same numbers up to summation order
         if dtype == torch.float32:
             assert (f - r_).abs().max().item() <= tol * scale, name
         else:       # bf16 activations flip the ReLU mask of a few near-zero pre-activations: compare in the L2 norm
