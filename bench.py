@@ -233,7 +233,7 @@ def main():
     # launches of one step / their summed device time, measured with hipEvents around each launch of ONE EXTRA step.
     # That step runs on EVERY rank (it issues the gradient all-reduces like any other step: rank 0 alone would leave the
     # other ranks' collectives unmatched); only rank 0 reports its timings.
-    roof = conv_roofline(model, trainer, x, y, args)
+    roof = step_roofline(model, trainer, x, y, args)
     out = None
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -272,63 +272,162 @@ def _eager_step(trainer, x, y):
         conv_mod.USE_WGRAD_STREAM[0] = side
 
 
-def conv_roofline(model, trainer, x, y, args):
-    """Times every MFMA convolution launch (fwd / dgrad / wgrad) of one train step with hipEvents recorded on
-    the launch stream, and divides their algorithmic FLOPs by the summed durations."""
-    import mrfp_amd.conv as conv_mod
+# ---------------------------------------------------------------------------------------------------------------------
+# Roofline of one train step, measured live: every C-ABI launch of ONE EXTRA eager step is attributed to a kernel family
+# (mrfp_amd._lib.HOOK sees the entry point's name and arguments right before it is called) and timed with hipEvents
+# recorded on the launch stream -- one event in front of every convolution launch and at every change of family
+# (consecutive launches of the other families share an interval: ~2 000 of them are a few microseconds long, and an event
+# pair around each would time the event markers, not the kernels).
+#   * MFMA family (the dominant one): conv forward / dgrad / wgrad; algorithmic FLOP = 2*MAC from the launch arguments.
+#   * HBM family "normalisation": statistics / finalize / apply passes (+ channel copies); algorithmic bytes = elements x
+#     sizeof x (tensor operands the launch reads or writes), from the launch arguments.
+#   * with --fourier: the build-defined Fourier amplitude mix (3 planes per call: x, the partner, y).
+# ---------------------------------------------------------------------------------------------------------------------
+CONV_CALLS = ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad")
+NORM_CALLS = ("mrfp_stats_fwd", "mrfp_stats_bwd", "mrfp_stats_bwd_mask", "mrfp_affine_fwd", "mrfp_affine_bwd",
+              "mrfp_affine_fwd_relu_mask", "mrfp_affine_bwd_mask", "mrfp_bn_finalize", "mrfp_bn_bwd_finalize", "mrfp_in_finalize",
+              "mrfp_in_bwd_finalize", "mrfp_np_finalize", "mrfp_np_bwd_finalize", "mrfp_mean_finalize", "mrfp_bn_eval_coef",
+              "mrfp_copy_channels")
+_TENSOR_ARGS = ("x", "res", "y", "dy", "dx", "dres", "src", "dst", "a", "b")
+
+
+def _family(name):
+    return "conv" if name in CONV_CALLS else "normalisation" if name in NORM_CALLS else \
+        "fourier" if name == "mrfp_fourier_mix" else "other"
+
+
+def _launch_work(name, d, esz):
+    """(algorithmic FLOP, algorithmic bytes) of one launch from its named arguments."""
+    if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated"):
+        M = d["B"] * d["Ho"] * d["Wo"]
+        flop = 2.0 * M * d["N"] * d["R"] * d["S"] * d["C"] / float(d["sstride"] * d["sstride"])
+        byts = esz * (d["B"] * d["H"] * d["W"] * d["C"] + M * d["N"] + d["N"] * d["R"] * d["S"] * d["C"]
+                      + (M * d["N"] if d.get("addend") else 0)) + (M * d["N"] / 8.0 if d.get("addend_mask") else 0)
+        return flop, byts
+    if name == "mrfp_conv_wgrad":
+        M = d["B"] * d["Ho"] * d["Wo"]
+        return (2.0 * M * d["N"] * d["R"] * d["S"] * d["C"],
+                esz * (d["B"] * d["H"] * d["W"] * d["C"] + M * d["N"]) + 4.0 * d["N"] * d["R"] * d["S"] * d["Ctrue"])
+    if name == "mrfp_fourier_mix":
+        return 0.0, 3.0 * esz * d["B"] * d["H"] * d["W"] * d["C"]
+    if name in NORM_CALLS:
+        if "ws" in d and "nslab" in d:                                   # finalize kernels: the partial sums
+            return 0.0, 8.0 * d["B"] * d["nslab"] * d["C"]
+        elems = (d["npix"] * d["C"] if "npix" in d else
+                 d["B"] * d.get("Ho", d.get("H", 0)) * d.get("Wo", d.get("W", 0)) * d["C"] if "B" in d else 0)
+        passes = sum(1 for k in _TENSOR_ARGS if d.get(k)) + (1.0 / (8 * esz) if d.get("mask") else 0.0)
+        return 0.0, esz * elems * passes
+    return 0.0, 0.0
+
+
+def step_roofline(model, trainer, x, y, args):
     from mrfp_amd import _lib
     timer = HipTimer()
-    events, flops, shapes = [], [], []
-    orig = _lib.call
     st = torch.cuda.current_stream().cuda_stream
+    esz = 4 if args.dtype == "f32" else 2
+    marks = []          # (event, family of the launches that follow it, [(name, named args)] for conv launches)
+    cur = [None]
 
-    def spy(name, *a):
-        if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad"):
-            if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated"):      # (the gated form: same leading arguments)
-                B, H, W, C, N, ldy, R, S, Ho, Wo = a[5:15]
-                f = 2.0 * B * Ho * Wo * N * R * S * C / float(a[19] * a[19])
-            else:
-                B, H, W, C, Ct, N, ldn, R, S, Ho, Wo = a[5:16]
-                f = 2.0 * B * Ho * Wo * N * R * S * C
-            e0, e1 = timer.event(), timer.event()
-            timer.record(e0, st)
-            r = orig(name, *a)
-            timer.record(e1, st)
-            events.append((e0, e1))
-            flops.append(f)
-            shapes.append(("mrfp_conv_fwd" if name == "mrfp_conv_fwd_gated" else name,
-                           [int(v) for v in a[5:20]]))
-            return r
-        return orig(name, *a)
-    conv_mod.call = spy
+    def hook(name, a):
+        fam = _family(name)
+        if fam == "conv" or fam != cur[0]:
+            e = timer.event()
+            timer.record(e, st)
+            marks.append([e, fam, []])
+            cur[0] = fam
+        marks[-1][2].append((name, dict(zip(_lib.ARG_NAMES[name], a))))
+    _lib.lib()
+    _lib.HOOK[0] = hook
     try:
         _eager_step(trainer, x, y)
-        torch.cuda.synchronize()
     finally:
-        conv_mod.call = orig
-    ms = [timer.elapsed_ms(a, b) for a, b in events]
-    tot_ms, tot_f = sum(ms), sum(flops)
+        _lib.HOOK[0] = None
+    end = timer.event()
+    timer.record(end, st)
+    torch.cuda.synchronize()
+    peak_f = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # f16 and bf16 MFMA: same dense rate
+    fam_ms, fam_bytes, fam_n = {}, {}, {}
+    convs = []
+    for i, (e, fam, calls) in enumerate(marks):
+        ms = timer.elapsed_ms(e, marks[i + 1][0] if i + 1 < len(marks) else end)
+        fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
+        fam_n[fam] = fam_n.get(fam, 0) + len(calls)
+        for name, d in calls:
+            fl, by = _launch_work(name, d, esz)
+            fam_bytes[fam] = fam_bytes.get(fam, 0.0) + by
+            if fam == "conv":
+                convs.append({"name": "mrfp_conv_fwd" if name == "mrfp_conv_fwd_gated" else name, "ms": ms, "flop": fl, "bytes": by,
+                              "args": [int(d[k]) for k in _lib.ARG_NAMES[name][5:20]] if name != "mrfp_conv_wgrad"
+                              else [int(d[k]) for k in _lib.ARG_NAMES[name][5:20]]})
+    tot_ms, tot_f = sum(c["ms"] for c in convs), sum(c["flop"] for c in convs)
     if args.dump_convs:
         with open(args.dump_convs, "w") as f:
-            json.dump([{"name": n, "args": sh, "ms": m, "tflops": fl / (m * 1e-3) / 1e12 if m > 0 else 0, "gflop": fl / 1e9}
-                       for (n, sh), m, fl in zip(shapes, ms, flops)], f)
-    peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # f16 and bf16 MFMA: same dense rate
+            json.dump([{"name": c["name"], "args": c["args"], "ms": c["ms"], "gflop": c["flop"] / 1e9, "mbytes": c["bytes"] / 1e6,
+                        "tflops": c["flop"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0} for c in convs], f)
     ach = tot_f / (tot_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(ms),
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_pw*_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(convs),
+            "achieved": round(ach, 2), "peak": peak_f, "unit": "TFLOP/s", "frac": round(ach / peak_f, 4),
             "traffic": None, "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3)}
-    roof.update(measured_traffic(args))
+    # every conv launch against ITS OWN bound: max(FLOP / MFMA peak, algorithmic bytes / HBM peak)
+    by_class = {}
+    for c in convs:
+        t_f, t_b = c["flop"] / (peak_f * 1e12), c["bytes"] / (PEAK_HBM_GBS * 1e9)
+        k = ("mfma_bound" if t_f >= t_b else "hbm_bound") + ("_wgrad" if c["name"] == "mrfp_conv_wgrad" else "_fwd_dgrad")
+        g = by_class.setdefault(k, {"launches": 0, "ms": 0.0, "tflop": 0.0, "gbytes": 0.0, "bound_ms": 0.0})
+        g["launches"] += 1
+        g["ms"] += c["ms"]
+        g["tflop"] += c["flop"] / 1e12
+        g["gbytes"] += c["bytes"] / 1e9
+        g["bound_ms"] += 1e3 * max(t_f, t_b)
+    for g in by_class.values():
+        g["frac_of_own_bound"] = round(g["bound_ms"] / g["ms"], 4) if g["ms"] > 0 else None
+        for k in ("ms", "tflop", "gbytes", "bound_ms"):
+            g[k] = round(g[k], 3)
+    roof["by_class"] = by_class
+    pmc = measured_traffic(args)
+    roof.update(pmc.get("conv", {}))
+
+    def hbm_entry(fam, what):
+        ms, by = fam_ms.get(fam, 0.0), fam_bytes.get(fam, 0.0)
+        if ms <= 0:
+            return None
+        gbs = by / (ms * 1e-3) / 1e9
+        e = {"bound": "hbm", "family": fam, "kernel": what, "launches": fam_n.get(fam, 0), "ms": round(ms, 3),
+             "bytes": round(by), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+             "traffic": None}
+        e.update(pmc.get(fam, {}))
+        return e
+    roof["hbm"] = hbm_entry("normalisation", "stats_kernel + *_finalize_kernel + affine_fwd/bwd_kernel + copy_channels_kernel")
+    if args.fourier:
+        roof["fourier"] = hbm_entry("fourier", "fft_rows / fft_cols_mix / dft_rows_inv kernels of mrfp_fourier_mix (3 planes per call)")
+    roof["other_ms_per_step"] = round(fam_ms.get("other", 0.0), 3)
     return roof
 
 
-def measured_traffic(args):
-    """HBM bytes of the conv kernel family per step from the PMC counters (TCC_EA0_RDREQ / WRREQ passes collected by
-    tools/measure_traffic.sh exactly as MI355X_MICROARCH.md prescribes, in their own rocprofv3 runs) -- read from the
-    committed profiles/r02_traffic.json, which names the commit and the workload it was measured on.  Counters cannot
-    be collected from inside this process, so the figure is attached only when that file describes THIS workload."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+def running_commit():
+    c = os.environ.get("MRFP_COMMIT")
+    if c:
+        return c
     try:
-        with open(path) as f:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def measured_traffic(args):
+    """HBM bytes per step by kernel family from the PMC counters (FETCH_SIZE / WRITE_SIZE passes collected by
+    tools/measure_traffic.sh exactly as MI355X_MICROARCH.md prescribes, in their own rocprofv3 runs) -- read from the newest
+    committed profiles/r*_traffic.json, which names the commit and the workload it was measured on.  Counters cannot be
+    collected from inside this process.  The figure is reported as `traffic` only when that file describes THIS workload AND
+    the commit it was measured at is the running tree's; kernels may have changed since otherwise, and it goes under
+    `traffic_reference` with the commit next to it."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files or args.fourier:
+        return {}
+    try:
+        with open(files[-1]) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return {}
@@ -336,9 +435,20 @@ def measured_traffic(args):
     if (w.get("trunk"), w.get("size"), w.get("width"), w.get("batch"), w.get("dtype")) != \
             (args.trunk, args.size, args.width or args.size, args.batch, args.dtype):
         return {}
-    return {"traffic": t.get("conv_family_hbm_bytes_per_step"), "traffic_unit": "bytes/step (conv kernel family, PMC)",
-            "traffic_algorithmic": t.get("conv_family_algorithmic_bytes_per_step"),
-            "traffic_measured_at_commit": t.get("commit"), "traffic_source": "profiles/r02_traffic.json"}
+    here = running_commit()
+    same = bool(here) and bool(t.get("commit")) and (here.startswith(t["commit"]) or t["commit"].startswith(here))
+    key = "traffic" if same else "traffic_reference"
+    out = {}
+    for fam in ("conv", "normalisation"):
+        hb = t.get("hbm_bytes_per_step", {}).get(fam)
+        if not hb:
+            continue
+        e = {key: hb["read"] + hb["write"], "traffic_unit": "bytes/step (%s kernel family, PMC FETCH_SIZE x2 + WRITE_SIZE)" % fam,
+             "traffic_measured_at_commit": t.get("commit"), "traffic_source": "profiles/" + os.path.basename(files[-1])}
+        if fam == "conv":
+            e["traffic_algorithmic"] = t.get("conv_family_algorithmic_bytes_per_step")
+        out[fam] = e
+    return out
 
 
 if __name__ == "__main__":

@@ -34,10 +34,12 @@ def parse_header(path: str = HEADER):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         restype = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}.get(ret.strip(), ctypes.c_char_p)
         argtypes = []
+        names = []
         for a in args.split(","):
             a = a.strip()
             if a in ("", "void"):
                 continue
+            names.append(re.split(r"[\s\*]+", a)[-1])
             if "*" in a:
                 argtypes.append(ctypes.c_void_p)
             elif a.startswith("int64_t"):
@@ -49,7 +51,11 @@ def parse_header(path: str = HEADER):
             else:
                 raise MrfpHipError("cannot parse argument %r of %s" % (a, name))
         protos[name] = (restype, argtypes)
+        ARG_NAMES[name] = names
     return protos
+
+
+ARG_NAMES = {}       # entry point -> argument names as the header spells them (measurement tooling: bench.py)
 
 
 _lib = None
@@ -97,10 +103,13 @@ def stream() -> int:
 
 
 _FN = {}
+HOOK = [None]        # measurement only (bench.py): hook(name, args) runs right BEFORE the entry point is called
 
 
 def call(name: str, *args):
     """Calls an int-returning entry point and raises with mrfp_last_error() on failure."""
+    if HOOK[0] is not None:
+        HOOK[0](name, args)
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(lib(), name)

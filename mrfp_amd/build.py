@@ -20,6 +20,7 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
@@ -58,6 +59,39 @@ def build(force: bool = False, always=()) -> str:
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     return LIB
+
+
+def build_variant(name: str, units, flags) -> str:
+    """csrc/libmrfp_hip_<name>.so: the translation units in `units` recompiled with the extra `flags`, every other object of the
+    default build reused.  Used for A/B runs of build-time switches on one GPU box (MRFP_HIP_LIB=<path>) and by the
+    conservative-wait build the tests compare the counted-vmcnt kernels with (-DMRFP_VMCNT0=1)."""
+    build()
+    objs = []
+    for s in _sources():
+        o = os.path.join(CSRC, s[:-4] + ".o")
+        if s[:-4] in units:
+            o = os.path.join(CSRC, "%s_%s.variant.o" % (s[:-4], name))
+            src = os.path.join(CSRC, s)
+            deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+            if not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps):
+                r = subprocess.run(["hipcc", *FLAGS, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc failed for %s (%s):\n%s\n%s" % (s, name, r.stdout, r.stderr))
+        objs.append(o)
+    lib = os.path.join(CSRC, "libmrfp_hip_%s.so" % name)
+    if not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        r = subprocess.run(["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed (%s):\n%s\n%s" % (name, r.stdout, r.stderr))
+    return lib
+
+
+# conservative-wait build: every counted `s_waitcnt vmcnt(N)` of the asynchronous LDS-DMA rings is vmcnt(0) (conv_common.hpp)
+VM0_UNITS = ("conv_pw", "conv_wgrad")
+
+
+def build_vm0() -> str:
+    return build_variant("vm0", VM0_UNITS, ["-DMRFP_VMCNT0=1"])
 
 
 if __name__ == "__main__":

@@ -261,3 +261,70 @@ def test_row_reuse_kernels_in_subprocess():
     env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="3")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Counted waits against the conservative build.  The asynchronous LDS-DMA rings (conv_pw.hip, and the
+# weight-gradient kernels where they use one) order their transfers with counted `s_waitcnt vmcnt(N)`; an under-wait shows
+# only when the race happens to fire.  libmrfp_hip_vm0.so is the same library with every counted wait replaced by vmcnt(0)
+# (-DMRFP_VMCNT0=1, built by __graft_entry__.build()): every pointwise launch shape of the bench workload -- forward with
+# fused statistics, dgrad, dgrad with a skip-gradient addend, weight gradient -- must give bit-identical results in both.
+# ---------------------------------------------------------------------------------------------------------------------
+_VM0_CODE = r"""
+import hashlib, json, sys, torch
+from mrfp_amd import conv
+shapes = json.load(open(sys.argv[1]))
+out = {}
+def h(t):
+    return hashlib.sha256(t.detach().contiguous().cpu().view(torch.uint8).numpy().tobytes()).hexdigest()
+for (B, H, W, C, N) in shapes:
+    g = torch.Generator(device='cuda').manual_seed(B + H + C + N)
+    x = torch.empty(B, C, H, W, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last).normal_(generator=g).requires_grad_(True)
+    w = (torch.empty(N, C, 1, 1, device='cuda').normal_(generator=g) * 0.05).requires_grad_(True)
+    gy = torch.empty(B, N, H, W, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last).normal_(generator=g)
+    gs = torch.empty(B, C, H, W, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last).normal_(generator=g)
+    for rep in range(2):
+        x.grad = None; w.grad = None
+        y, xs = conv.conv2d(x, w, None, 1, 0, 1, want_skip=True)
+        st = y._mrfp_colstats[0].clone()
+        torch.autograd.backward([y, xs], [gy, gs])          # dgrad with the skip gradient as its epilogue addend + wgrad
+        key = '%dx%dx%dx%d->%d' % (B, H, W, C, N)
+        rec = [h(y), h(st), h(x.grad), h(w.grad)]
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = conv.conv2d(x2, w.detach(), None, 1, 0, 1)
+        y2.backward(gy)                                       # plain dgrad
+        rec.append(h(x2.grad))
+        assert out.setdefault(key, rec) == rec, ('run-to-run difference', key)
+torch.cuda.synchronize()
+json.dump(out, open(sys.argv[2], 'w'))
+"""
+
+
+def test_counted_waits_equal_the_vmcnt0_build(tmp_path):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vm0 = os.path.join(root, "mrfp_amd", "csrc", "libmrfp_hip_vm0.so")
+    assert os.path.exists(vm0), "libmrfp_hip_vm0.so is not built (__graft_entry__.build() / mrfp_amd.build.build_vm0())"
+    shapes = set()
+    for name, a in json.load(open(os.path.join(root, "tools", "bench_conv_shapes.json"))):
+        B, H, W, C, N, ldy, R, S, Ho, Wo, stride = a[:11]
+        if name == "mrfp_conv_fwd" and R == 1 and S == 1 and stride == 1 and a[14] == 1 and H > 1 and C % 64 == 0 and N % 8 == 0:
+            shapes.add((min(B, 4) if H * W >= 96 * 96 else B, H, W, C, N))      # (the big maps: 4 images are enough tiles)
+    shapes = sorted(shapes)
+    assert len(shapes) >= 8, shapes
+    sf = tmp_path / "shapes.json"
+    sf.write_text(json.dumps(shapes))
+    res = []
+    for tag, extra in (("default", {}), ("vm0", {"MRFP_HIP_LIB": vm0})):
+        out = tmp_path / (tag + ".json")
+        env = dict(os.environ, PYTHONPATH=root, **extra)
+        env.pop("MRFP_HIP_LIB", None) if not extra else None
+        r = subprocess.run([sys.executable, "-c", _VM0_CODE, str(sf), str(out)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (tag, r.stdout[-500:], r.stderr[-2000:])
+        res.append(json.loads(out.read_text()))
+    assert res[0].keys() == res[1].keys() and len(res[0]) == len(shapes)
+    bad = [k for k in res[0] if res[0][k] != res[1][k]]
+    assert not bad, bad

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Folds the rocprofv3 outputs of tools/measure_traffic.sh into
-  gpurun_out/traffic_r02/r02_bench_kernel_stats.{csv,md}   per-kernel device time of the bench command
-  gpurun_out/traffic_r02/r02_traffic.json                   HBM bytes per train step by kernel family (PMC)
+"""Folds the rocprofv3 outputs of tools/measure_traffic.sh into (TAG = $MRFP_ROUND, default r03)
+  gpurun_out/traffic_TAG/TAG_bench_kernel_stats.{csv,md}   per-kernel device time of the bench command
+  gpurun_out/traffic_TAG/TAG_traffic.json                   HBM bytes per train step by kernel family (PMC), and the conv
+                                                            launches of one step classed by their OWN bound (by_class)
 (copy them into profiles/ to have them judged / read by bench.py).
 
 Corrections, exactly as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE and WRITE_SIZE are reported in KB; on gfx950
@@ -15,7 +16,8 @@ import os
 import subprocess
 import sys
 
-FAMILIES = (("conv", ("conv_igemm_kernel", "conv_wgrad_kernel", "wgrad_reduce_kernel", "conv1x1_bstat_kernel", "compact_stats_kernel")),
+TAG = os.environ.get("MRFP_ROUND", "r03")
+FAMILIES = (("conv", ("conv_igemm_kernel", "conv_wgrad_kernel", "wgrad_reduce_kernel", "conv1x1_bstat_kernel", "conv_pw", "compact_stats_kernel")),
             ("normalisation", ("stats_kernel", "affine_fwd_kernel", "affine_bwd_kernel", "finalize_kernel", "copy_channels_kernel")),
             )
 
@@ -38,10 +40,10 @@ def main(out, steps_stats, steps_pmc):
     fam_ms = {}
     for r in rows:
         fam_ms[family(r["Name"])] = fam_ms.get(family(r["Name"]), 0.0) + float(r["TotalDurationNs"]) / 1e6 / steps_stats
-    with open(out + "/r02_bench_kernel_stats.csv", "w") as f:
+    with open(out + "/%s_bench_kernel_stats.csv" % TAG, "w") as f:
         f.write(open(path).read())
-    with open(out + "/r02_bench_kernel_stats.md", "w") as f:
-        f.write("# Round 2 -- `MRFP_WGRAD_STREAM=0 python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline` under rocprofv3 "
+    with open(out + "/%s_bench_kernel_stats.md" % TAG, "w") as f:
+        f.write("# " + TAG + " -- `MRFP_WGRAD_STREAM=0 python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline` under rocprofv3 "
                 "--kernel-trace --stats (ResNet-101 MRFP+ 16x768x768 bf16, one MI355X, commit %s)\n\n" % commit)
         f.write("%d train steps in the trace (warm-up, timed, and the per-launch timing step of bench.py); total GPU kernel "
                 "time %.2f ms = %.2f ms/step.  By family (ms/step): %s\n\n" % (
@@ -75,17 +77,27 @@ def main(out, steps_stats, steps_pmc):
     # (+ the skip-gradient addend, + the split-K slabs written and re-read) -- taken from a --dump-convs file when present
     dump = os.path.join(out, "convs.json")
     if os.path.exists(dump):
-        alg = 0.0
+        # algorithmic bytes of the conv family (every launch reads its input + weights (+ addend) and writes its output once)
+        # and the per-class breakdown bench.py prints as roofline.by_class: each launch against max(FLOP / 2.5 PF, bytes / 8 TB/s)
+        alg, cls = 0.0, {}
         for e in json.load(open(dump)):
-            a = e["args"]
-            if e["name"] == "mrfp_conv_fwd":
-                B, H, W, C, N, ldy, R, S, Ho, Wo = a[:10]
-                alg += 2.0 * (B * H * W * C + B * Ho * Wo * N + N * R * S * C)
-            elif e["name"] == "mrfp_conv_wgrad":
-                B, H, W, C, Ct, N, ldn, R, S, Ho, Wo = a[:11]
-                alg += 2.0 * (B * H * W * C + B * Ho * Wo * N) + 4.0 * N * R * S * C
+            by, fl = e["mbytes"] * 1e6, e["gflop"] * 1e9
+            alg += by
+            t_f, t_b = fl / 2.5e15, by / 8.0e12
+            k = ("mfma_bound" if t_f >= t_b else "hbm_bound") + ("_wgrad" if e["name"] == "mrfp_conv_wgrad" else "_fwd_dgrad")
+            g = cls.setdefault(k, {"launches": 0, "ms": 0.0, "tflop": 0.0, "gbytes": 0.0, "bound_ms": 0.0})
+            g["launches"] += 1
+            g["ms"] += e["ms"]
+            g["tflop"] += fl / 1e12
+            g["gbytes"] += by / 1e9
+            g["bound_ms"] += 1e3 * max(t_f, t_b)
+        for g in cls.values():
+            g["frac_of_own_bound"] = round(g["bound_ms"] / g["ms"], 4)
+            for k in ("ms", "tflop", "gbytes", "bound_ms"):
+                g[k] = round(g[k], 3)
         traffic["conv_family_algorithmic_bytes_per_step"] = round(alg)
-    json.dump(traffic, open(out + "/r02_traffic.json", "w"), indent=1)
+        traffic["conv_by_class"] = cls
+    json.dump(traffic, open(out + "/%s_traffic.json" % TAG, "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
 
