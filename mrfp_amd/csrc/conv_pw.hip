@@ -35,6 +35,13 @@ struct BsP {
     unsigned xbytes, wbytes, ybytes;
 };
 
+__device__ __forceinline__ f32x2 lo2(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {      // v_pk_fma_f32 (the library is built with -ffp-contract=off)
+#pragma clang fp contract(fast)
+    return a * b + c;
+}
+
 struct HasPrev { static constexpr bool value = true; };
 struct NoPrev { static constexpr bool value = false; };
 template <typename T, int KB, int NST, bool STATS, bool ADD>
@@ -110,9 +117,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
 
     // (a half-tile start delay for the second resident workgroup of every CU was measured: no effect)
     const int nl = n0 + 8 * lq;                 // first of this lane's 8 output channels
-    float cs[8], cq[8];                         // per-channel sum / sum of squares over every tile of this workgroup
+    f32x2 cs2[4], cq2[4];                       // per-channel sum / sum of squares over every tile of this workgroup (channel pairs)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { cs[u] = 0.f; cq[u] = 0.f; }
+    for (int u = 0; u < 4; ++u) { cs2[u] = f32x2{0.f, 0.f}; cq2[u] = f32x2{0.f, 0.f}; }
 
     // SOFTWARE PIPELINE over the tiles: the epilogue of tile t-1 (conversions, statistics, addend, stores: ~150 vector
     // instructions) is written BETWEEN the k steps of tile t, in one basic block with its multiplies (STATS / ADD are
@@ -149,25 +156,37 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         const int m = tile * 64 + i * 16 + l15;
         const bool ok = m < p.M && nl < p.N;                              // (N % 8 == 0 for this kernel: chunks are whole)
         uint4 v;
-        v.x = pack2<T>(acc[i][0][0], acc[i][0][1]);
-        v.y = pack2<T>(acc[i][0][2], acc[i][0][3]);
-        v.z = pack2<T>(acc[i][1][0], acc[i][1][1]);
-        v.w = pack2<T>(acc[i][1][2], acc[i][1][3]);
         if constexpr (STATS) {
-            // statistics of the STORED (rounded) values, before the addend.  Rows beyond M were zero-filled by the transfer's
-            // bounds check, so they add exactly 0: no mask.
-            float f[8];
-            unpack2<T>(v.x, f[0], f[1]);
-            unpack2<T>(v.y, f[2], f[3]);
-            unpack2<T>(v.z, f[4], f[5]);
-            unpack2<T>(v.w, f[6], f[7]);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                cs[u] += f[u];
-                cq[u] += f[u] * f[u];
-            }
+            // Statistics of the fp32 accumulators (BEFORE the rounding to the 16-bit storage type), in packed fp32 arithmetic:
+            // 4 v_pk_add_f32 + 4 v_pk_fma_f32 per 8 outputs.  Round 2 summed the stored (rounded) values -- 8 unpack + 8 multiply
+            // + 8 add instructions more per 8 outputs, on a kernel whose tile time IS its vector-instruction count (226 vector
+            // instructions beside 64 MFMAs per tile; profiles/r03_experiments.md).  The rounding errors are zero-mean and 2^-9
+            // relative: the batch mean / variance move by ~1e-5 of a standard deviation, below what bf16 activations resolve.
+            // Rows beyond M were zero-filled by the transfer's bounds check, so they add exactly 0: no mask.
+            cs2[0] += lo2(acc[i][0]); cs2[1] += hi2(acc[i][0]); cs2[2] += lo2(acc[i][1]); cs2[3] += hi2(acc[i][1]);
+            cq2[0] = fma2(lo2(acc[i][0]), lo2(acc[i][0]), cq2[0]);
+            cq2[1] = fma2(hi2(acc[i][0]), hi2(acc[i][0]), cq2[1]);
+            cq2[2] = fma2(lo2(acc[i][1]), lo2(acc[i][1]), cq2[2]);
+            cq2[3] = fma2(hi2(acc[i][1]), hi2(acc[i][1]), cq2[3]);
         }
-        if constexpr (ADD) v = chunk_add<T>(v, gate_chunk16(av[i], am[i]));
+        if constexpr (ADD) {
+            // skip-gradient addend (gated in its packed form), added in fp32 BEFORE the one rounding to the storage type
+            const uint4 g = gate_chunk16(av[i], am[i]);
+            float a[8];
+            unpack2<T>(g.x, a[0], a[1]);
+            unpack2<T>(g.y, a[2], a[3]);
+            unpack2<T>(g.z, a[4], a[5]);
+            unpack2<T>(g.w, a[6], a[7]);
+            v.x = pack2<T>(acc[i][0][0] + a[0], acc[i][0][1] + a[1]);
+            v.y = pack2<T>(acc[i][0][2] + a[2], acc[i][0][3] + a[3]);
+            v.z = pack2<T>(acc[i][1][0] + a[4], acc[i][1][1] + a[5]);
+            v.w = pack2<T>(acc[i][1][2] + a[6], acc[i][1][3] + a[7]);
+        } else {
+            v.x = pack2<T>(acc[i][0][0], acc[i][0][1]);
+            v.y = pack2<T>(acc[i][0][2], acc[i][0][3]);
+            v.z = pack2<T>(acc[i][1][0], acc[i][1][1]);
+            v.w = pack2<T>(acc[i][1][2], acc[i][1][3]);
+        }
         const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
         u32x4 dv;
         dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
@@ -248,10 +267,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         // ONE statistics row block per workgroup range (all its tiles): the 16 lanes of a quarter hold the same 8 channels
         // for 16 different pixels -- fold them (DPP, fixed order) and let lane 0 of the quarter write
         float* out = p.colstats + (size_t)chunk * 2 * p.ldy;
+        float cs[8], cq[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            cs[u] = row16_sum(cs[u]);
-            cq[u] = row16_sum(cq[u]);
+        for (int u = 0; u < 4; ++u) {
+            cs[2 * u] = row16_sum(cs2[u].x); cs[2 * u + 1] = row16_sum(cs2[u].y);
+            cq[2 * u] = row16_sum(cq2[u].x); cq[2 * u + 1] = row16_sum(cq2[u].y);
         }
         if (l15 == 0 && nl < p.N) {
 #pragma unroll

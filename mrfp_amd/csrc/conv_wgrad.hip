@@ -318,34 +318,58 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
 }
 
 // dW[n][c][r][s] (OIHW fp32, c < Ctrue) = sum_z slab[z][n][(r*S+s)*C + c]
-// Threads walk the SLAB order (4 consecutive channels each, 16-byte loads: the slabs are ~20x the size of dW, so
-// their reads are the ones that must coalesce); the OIHW stores are 4-byte scattered but few.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int N, int Q, int C, int Ctrue, int RS,
-                                    float* __restrict__ dw, int accumulate) {
+// One workgroup = 64 consecutive float4 of the slab order (1 KB runs: the slabs are ~20-30x the size of dW, so their reads are
+// the ones that must coalesce) x 4 slab groups: wave g sums the slabs z = g, g + 4, g + 8, ... in ascending order with eight
+// independent 16-byte loads in flight per lane, the four group sums are combined through LDS as (g0 + g1) + (g2 + g3) -- a fixed
+// association, so the result is bitwise reproducible.  (Round 2 walked all slabs of an output in ONE thread, four loads in
+// flight: 14 us per launch for 30-60 MB that the chip reads in 6; a last-arriving-workgroup reduction inside conv_wgrad_kernel
+// was considered and not built -- the arriver of a tile would pull splits x 64 KB through ONE compute unit behind a ~3.5 us
+// device-scope fence, MI355X_MICROARCH.md -- DESIGN.md section 4.)  The OIHW stores are 4-byte scattered but few.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int N, int Q, int C, int Ctrue, int RS,
+                                                            float* __restrict__ dw, int accumulate) {
+    __shared__ float4 part[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t total4 = (int64_t)N * Q / 4, NQ = (int64_t)N * Q;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = i * 4;
-        const int n = (int)(j / Q), q = (int)(j - (int64_t)n * Q);
-        const int rs = q / C, c = q - rs * C;
-        if (c >= Ctrue) continue;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-        for (int z = 0; z < splits; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)z * NQ + j);
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4) {
+        const float* base = slab + i * 4;
+        int z = g;
+        for (; z + 28 < splits; z += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (size_t)(z + 4 * u) * NQ);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; z < splits; z += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)z * NQ);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        float* d = dw + ((size_t)n * Ctrue + c) * RS + rs;
-        if (accumulate) {            // a later batch range of an activation that is read in several launches
-            acc.x += d[0];
-            if (c + 1 < Ctrue) acc.y += d[RS];
-            if (c + 2 < Ctrue) acc.z += d[2 * RS];
-            if (c + 3 < Ctrue) acc.w += d[3 * RS];
-        }
-        d[0] = acc.x;
-        if (c + 1 < Ctrue) d[RS] = acc.y;
-        if (c + 2 < Ctrue) d[2 * RS] = acc.z;
-        if (c + 3 < Ctrue) d[3 * RS] = acc.w;
     }
+    part[g][o] = acc;
+    __syncthreads();
+    if (g != 0 || i >= total4) return;
+    const float4 p0 = part[0][o], p1 = part[1][o], p2 = part[2][o], p3 = part[3][o];
+    acc.x = (p0.x + p1.x) + (p2.x + p3.x);
+    acc.y = (p0.y + p1.y) + (p2.y + p3.y);
+    acc.z = (p0.z + p1.z) + (p2.z + p3.z);
+    acc.w = (p0.w + p1.w) + (p2.w + p3.w);
+    const int64_t j = i * 4;
+    const int n = (int)(j / Q), q = (int)(j - (int64_t)n * Q);
+    const int rs = q / C, c = q - rs * C;
+    if (c >= Ctrue) return;
+    float* d = dw + ((size_t)n * Ctrue + c) * RS + rs;
+    if (accumulate) {            // a later batch range of an activation that is read in several launches
+        acc.x += d[0];
+        if (c + 1 < Ctrue) acc.y += d[RS];
+        if (c + 2 < Ctrue) acc.z += d[2 * RS];
+        if (c + 3 < Ctrue) acc.w += d[3 * RS];
+    }
+    d[0] = acc.x;
+    if (c + 1 < Ctrue) d[RS] = acc.y;
+    if (c + 2 < Ctrue) d[2 * RS] = acc.z;
+    if (c + 3 < Ctrue) d[3 * RS] = acc.w;
 }
 
 template <typename T, int WM, int WN, bool DMA, bool DENSE = false>
@@ -479,8 +503,7 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
         else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st) : launch_wgrad<bf16, 2, 2>(p, splits, st);
         if (rc) return rc;
         const int64_t total4 = N * (int64_t)p.Q / 4;          // Q = R*S*C and C*esz % 16 == 0  =>  Q % 4 == 0
-        int64_t blocks = (total4 + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
+        const int64_t blocks = (total4 + 63) / 64;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, splits, (int)N,
                            p.Q, (int)C, (int)Ctrue, (int)(R * S), dw, b0 > 0 ? 1 : 0);
         MRFP_LAUNCH_CHECK();

@@ -112,9 +112,12 @@ def test_padded_logits_path():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 64, 20, 18, 128, 3), (3, 128, 33, 31, 64, 1), (2, 128, 240, 240, 256, 3)])
+@pytest.mark.parametrize("case", [(2, 64, 20, 18, 128, 3), (3, 128, 33, 31, 64, 1), (2, 128, 240, 240, 256, 3), (2, 128, 48, 40, 256, 1),
+                                  (4, 256, 48, 48, 1024, 1)])
 def test_conv_epilogue_statistics_feed_batchnorm(dtype, case):
-    """BatchNorm statistics fused into the producing conv's epilogue == the separate statistics pass."""
+    """BatchNorm statistics fused into the producing conv's epilogue == the separate statistics pass.  (The 16-bit pointwise
+    kernels of conv_pw.hip sum their fp32 accumulators, the separate pass the rounded stored values: zero-mean rounding errors of
+    2^-9 relative, i.e. ~1e-5 of a standard deviation in the batch mean -- the last two cases, with their own tolerance.)"""
     from mrfp_amd import conv, ops
     B, Cin, H, W, Cout, k = case
     g = torch.Generator().manual_seed(7)
@@ -134,7 +137,10 @@ def test_conv_epilogue_statistics_feed_batchnorm(dtype, case):
     conv.FUSE_STATS[0] = True
     assert torch.equal(y1, y2)
     assert relerr(z1, z2) < (1e-5 if dtype == torch.float32 else 1e-2)
-    assert relerr(rm1, rm2) < 1e-5 and relerr(rv1, rv2) < 1e-4
+    pw16 = dtype != torch.float32 and k == 1 and Cout >= 128
+    assert relerr(rm1, rm2) < (5e-3 if pw16 else 1e-5) and relerr(rv1, rv2) < (1e-3 if pw16 else 1e-4)
+    if pw16:          # the mean itself, against the spread of the channel: ~1e-5 standard deviations
+        assert float(((rm1 - rm2).abs() / (0.1 * ((rv1 - 0.9) / 0.1).clamp_min(1e-12).sqrt())).max()) < 2e-4
 
 
 def test_alternative_tile_variants_in_subprocess():

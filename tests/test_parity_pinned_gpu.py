@@ -274,8 +274,8 @@ def _check_grads_elementwise(params, og, what):
         assert got is not None and tuple(got.shape) == tuple(ref64.shape), (what, k)
         noise = (g32[k] - ref64).norm().item() / n64
         err = (got.detach().double().cpu() - ref64).norm().item() / n64
-        assert err < 3e-2, (what, k, err, noise)
-        if err > 3 * noise + 2e-4:
+        assert err < 3e-2 + 2 * noise, (what, k, err, noise)      # (stem-side tensors in front of an InstanceNorm: the reference's
+        if err > 3 * noise + 2e-4:                                #  own fp32 run is 2.6e-2 from the fp64 value there)
             outside.append((k, err, noise))
     assert n_t >= 300 and len(outside) <= 0.02 * n_t, (what, n_t, outside)
 
