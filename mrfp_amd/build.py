@@ -12,6 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmrfp_hip.so")
 ARCH = "gfx950"
+# (-fno-slp-vectorize -- no v_pk_add_f32 / v_pk_mul_f32 from the SLP vectoriser -- was measured in round 3: the bench step is the
+#  same with and without, 57.61 / 57.63 ms on one box; profiles/r03_experiments.md)
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

@@ -35,13 +35,6 @@ struct BsP {
     unsigned xbytes, wbytes, ybytes;
 };
 
-__device__ __forceinline__ f32x2 lo2(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
-__device__ __forceinline__ f32x2 hi2(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {      // v_pk_fma_f32 (the library is built with -ffp-contract=off)
-#pragma clang fp contract(fast)
-    return a * b + c;
-}
-
 struct HasPrev { static constexpr bool value = true; };
 struct NoPrev { static constexpr bool value = false; };
 template <typename T, int KB, int NST, bool STATS, bool ADD>
@@ -117,9 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
 
     // (a half-tile start delay for the second resident workgroup of every CU was measured: no effect)
     const int nl = n0 + 8 * lq;                 // first of this lane's 8 output channels
-    f32x2 cs2[4], cq2[4];                       // per-channel sum / sum of squares over every tile of this workgroup (channel pairs)
+    float cs[8], cq[8];                         // per-channel sum / sum of squares over every tile of this workgroup
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { cs2[u] = f32x2{0.f, 0.f}; cq2[u] = f32x2{0.f, 0.f}; }
+    for (int u = 0; u < 8; ++u) { cs[u] = 0.f; cq[u] = 0.f; }
 
     // SOFTWARE PIPELINE over the tiles: the epilogue of tile t-1 (conversions, statistics, addend, stores: ~150 vector
     // instructions) is written BETWEEN the k steps of tile t, in one basic block with its multiplies (STATS / ADD are
@@ -157,17 +150,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         const bool ok = m < p.M && nl < p.N;                              // (N % 8 == 0 for this kernel: chunks are whole)
         uint4 v;
         if constexpr (STATS) {
-            // Statistics of the fp32 accumulators (BEFORE the rounding to the 16-bit storage type), in packed fp32 arithmetic:
-            // 4 v_pk_add_f32 + 4 v_pk_fma_f32 per 8 outputs.  Round 2 summed the stored (rounded) values -- 8 unpack + 8 multiply
-            // + 8 add instructions more per 8 outputs, on a kernel whose tile time IS its vector-instruction count (226 vector
-            // instructions beside 64 MFMAs per tile; profiles/r03_experiments.md).  The rounding errors are zero-mean and 2^-9
+            // Statistics of the fp32 accumulators (BEFORE the rounding to the 16-bit storage type): 8 v_add_f32 + 8 v_fma_f32 per 8
+            // outputs, SCALAR on purpose (packed v_pk_* fp32 arithmetic is an anti-lever beside MFMAs on gfx950:
+            // MI355X_MICROARCH.md).  Round 2 summed the stored (rounded) values -- 8 unpack + 8 multiply instructions more per 8
+            // outputs, and the compiler packed its adds into v_pk_add_f32 (profiles/r03_experiments.md).  The rounding errors are zero-mean and 2^-9
             // relative: the batch mean / variance move by ~1e-5 of a standard deviation, below what bf16 activations resolve.
             // Rows beyond M were zero-filled by the transfer's bounds check, so they add exactly 0: no mask.
-            cs2[0] += lo2(acc[i][0]); cs2[1] += hi2(acc[i][0]); cs2[2] += lo2(acc[i][1]); cs2[3] += hi2(acc[i][1]);
-            cq2[0] = fma2(lo2(acc[i][0]), lo2(acc[i][0]), cq2[0]);
-            cq2[1] = fma2(hi2(acc[i][0]), hi2(acc[i][0]), cq2[1]);
-            cq2[2] = fma2(lo2(acc[i][1]), lo2(acc[i][1]), cq2[2]);
-            cq2[3] = fma2(hi2(acc[i][1]), hi2(acc[i][1]), cq2[3]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cs[u] += acc[i][0][u];
+                cs[4 + u] += acc[i][1][u];
+                cq[u] = __builtin_fmaf(acc[i][0][u], acc[i][0][u], cq[u]);
+                cq[4 + u] = __builtin_fmaf(acc[i][1][u], acc[i][1][u], cq[4 + u]);
+            }
         }
         if constexpr (ADD) {
             // skip-gradient addend (gated in its packed form), added in fp32 BEFORE the one rounding to the storage type
@@ -267,11 +262,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         // ONE statistics row block per workgroup range (all its tiles): the 16 lanes of a quarter hold the same 8 channels
         // for 16 different pixels -- fold them (DPP, fixed order) and let lane 0 of the quarter write
         float* out = p.colstats + (size_t)chunk * 2 * p.ldy;
-        float cs[8], cq[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            cs[2 * u] = row16_sum(cs2[u].x); cs[2 * u + 1] = row16_sum(cs2[u].y);
-            cq[2 * u] = row16_sum(cq2[u].x); cq[2 * u + 1] = row16_sum(cq2[u].y);
+        for (int u = 0; u < 8; ++u) {
+            cs[u] = row16_sum(cs[u]);
+            cq[u] = row16_sum(cq[u]);
         }
         if (l15 == 0 && nl < p.N) {
 #pragma unroll
