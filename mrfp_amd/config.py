@@ -56,6 +56,11 @@ cfg.MODEL.FUSE_UPSAMPLE_CE = True
 # MRFP+ head: evaluate final2(Upsample(dec1) + OCout_dec) as Upsample(final2(dec1)) + final2(OCout_dec) (a 1x1 conv
 # commutes with bilinear interpolation): the 2x upsample runs on the class scores, not on 256 channels
 cfg.MODEL.COMMUTE_O2 = __import__("os").environ.get("MRFP_COMMUTE_O2", "1") != "0"
+# decoder input cat([bot_fine(low level) 48, Upsample(bot_aspp) 256]) = 304 channels: carried as 320 (zero channels behind the
+# 304; the 304-channel weight of final1[0] is zero-padded in its packs, the state_dict keeps the reference shape) so that its
+# K dimension is whole 128-byte tiles -- aligned / row-reuse convolution kernels instead of the per-thread tap tracking of the
+# unaligned ones.  1 = the reference's 304.
+cfg.MODEL.DECODER_PAD = int(__import__("os").environ.get("MRFP_DECODER_PAD", "64"))
 # directory searched for ImageNet checkpoints when pretrained=True (no network access here)
 cfg.MODEL.PRETRAINED_DIR = None
 

@@ -59,7 +59,10 @@ def get_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, Cphys: i
     if pk is None:
         pk = _Pack()
         pk.wf = torch.empty(Nphys * R * S * Cphys, dtype=dtype, device=dev)
-        pk.wd = torch.empty(C * R * S * Nphys, dtype=dtype, device=dev)
+        # dgrad pack [Cphys][R][S][Nphys]: the rows of pad input channels (c >= C) stay zero, so a dgrad launch over a
+        # channel-padded input writes exact zeros into the pad channels of dx
+        pk.wd = (torch.zeros(Cphys * R * S * Nphys, dtype=dtype, device=dev) if Cphys != C
+                 else torch.empty(C * R * S * Nphys, dtype=dtype, device=dev))
         pk.bias = None
         pk.version = None
         pk.wref = weakref.ref(weight)
@@ -242,8 +245,6 @@ class _Conv2d(torch.autograd.Function):
         N, C, R, S = weight.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if Cphys != C:
-                raise _lib.MrfpHipError("dgrad through a channel-padded input is not supported")
             pk = get_pack(weight, bias, x.dtype, Cphys, Nphys)
             dx = empty_cl(B, Cphys, H, W, x.dtype, x.device)
             gate = None

@@ -381,7 +381,7 @@ class MRFPPlus(_DeepLabBase):
         t = self.aspp(t)
         self._tap("aspp", t)
         dec0_up = self.bot_aspp(t)
-        dec1 = self._final1(ops.concat_upsample(dec0_fine, dec0_up, low_level.shape[2:]))     # cat([dec0_fine, Upsample(dec0_up)], 1)
+        dec1 = self._final1(ops.concat_upsample(dec0_fine, dec0_up, low_level.shape[2:], cfg.MODEL.DECODER_PAD))   # cat([dec0_fine, Upsample(dec0_up)], 1)
         self._tap("dec1", dec1)
         if o2:                                         # "+" of MRFP+: deepv3.py:355-357
             if cfg.MODEL.COMMUTE_O2:
@@ -414,5 +414,5 @@ class simpleDeepV3Plus(_DeepLabBase):
         x_tuple = self.layer4(self.layer3(self.layer2(x_tuple)))
         dec0_up = self.bot_aspp(self.aspp(x_tuple[0]))
         dec0_fine = self.bot_fine(low_level)
-        dec1 = self._final1(ops.concat_upsample(dec0_fine, dec0_up, low_level.shape[2:]))      # cat([dec0_fine, Upsample(dec0_up)], 1)
+        dec1 = self._final1(ops.concat_upsample(dec0_fine, dec0_up, low_level.shape[2:], cfg.MODEL.DECODER_PAD))    # cat([dec0_fine, Upsample(dec0_up)], 1)
         return self._head(dec1, (h, w), gts, training)

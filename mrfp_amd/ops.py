@@ -750,25 +750,27 @@ class _ConcatUpsample(torch.autograd.Function):
     upsampled map (302 MB at 16 x 192 x 192) is never copied in either direction."""
 
     @staticmethod
-    def forward(ctx, a, b, Ho, Wo):
+    def forward(ctx, a, b, Ho, Wo, pad_to):
         a, b = _chk(a), _chk(b)
         B, Ca, H, W = a.shape
         _, Cb, Hi, Wi = b.shape
         if (H, W) != (Ho, Wo) or b.shape[0] != B or a.dtype != b.dtype:
             raise _lib.MrfpHipError("concat_upsample: shape / dtype mismatch")
-        Ct = Ca + Cb
+        Ct = (Ca + Cb + pad_to - 1) // pad_to * pad_to          # physical channels: [a | Upsample(b) | zeros]
         y = empty_cl(B, Ct, H, W, a.dtype, a.device)
         esz = a.element_size()
+        if Ct != Ca + Cb:
+            y[:, Ca + Cb:].zero_()
         call("mrfp_copy_channels", ptr(a), ptr(y), dt(a), B * H * W, Ca, Ca, 0, Ct, 0, stream())
         call("mrfp_bilinear_fwd_into", ptr(b), y.data_ptr() + Ca * esz, dt(b), B, Hi, Wi, Ho, Wo, Cb, Cb, Ct, stream())
-        ctx.dims = (B, Ca, Cb, Hi, Wi, Ho, Wo)
+        ctx.dims = (B, Ca, Cb, Hi, Wi, Ho, Wo, Ct)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = _chk(dy, "dy")
-        B, Ca, Cb, Hi, Wi, Ho, Wo = ctx.dims
-        Ct, esz = Ca + Cb, dy.element_size()
+        B, Ca, Cb, Hi, Wi, Ho, Wo, Ct = ctx.dims
+        esz = dy.element_size()
         da = db = None
         if ctx.needs_input_grad[0]:
             da = empty_cl(B, Ca, Ho, Wo, dy.dtype, dy.device)
@@ -776,16 +778,19 @@ class _ConcatUpsample(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             db = empty_cl(B, Cb, Hi, Wi, dy.dtype, dy.device)
             call("mrfp_bilinear_bwd_from", dy.data_ptr() + Ca * esz, ptr(db), dt(dy), B, Hi, Wi, Ho, Wo, Cb, Cb, Ct, stream())
-        return da, db, None, None
+        return da, db, None, None, None
 
 
-def concat_upsample(a, b, size):
+def concat_upsample(a, b, size, pad_to=1):
     """concat_channels([a, upsample_bilinear(b, size)]) without materialising the upsampled map on its own.  Needs both
-    channel counts to be whole 16-byte chunks (else the plain composition runs)."""
+    channel counts to be whole 16-byte chunks (else the plain composition runs).  pad_to > 1: the result carries zero
+    channels up to the next multiple of pad_to (the consuming convolution takes a channel-padded input: its weight pack is
+    zero-padded to match) -- the decoder's 48 + 256 = 304 channels become 320 = whole 128-byte K tiles, which puts its 3x3
+    convolution, dgrad and wgrad on the aligned / row-reuse kernels."""
     epc = 16 // a.element_size()
     if a.shape[1] % epc or b.shape[1] % epc or (b.shape[2] == 1 and b.shape[3] == 1):
         return concat_channels([a, upsample_bilinear(b, size)])
-    return _ConcatUpsample.apply(a, b, int(size[0]), int(size[1]))
+    return _ConcatUpsample.apply(a, b, int(size[0]), int(size[1]), int(pad_to))
 
 
 def concat_channels(tensors):

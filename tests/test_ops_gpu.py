@@ -495,3 +495,33 @@ def test_concat_upsample_equals_the_composition(dtype):
         assert torch.equal(u, v)
     yc = torch.cat([a, F.interpolate(b, size=(24, 20), mode="bilinear", align_corners=True)], 1)
     assert relerr(outs[0][0], yc) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_padded_decoder_concat_feeds_a_channel_padded_convolution(dtype):
+    """cfg.MODEL.DECODER_PAD: cat([a 48, Upsample(b) 256]) carried as 320 channels (zeros behind the 304) into the 304-channel 3x3
+    convolution of the decoder (reference deepv3.py:200-208, 349-353): forward, the gradients of a and b (dgrad over a
+    channel-padded input: its pad channels come out exactly zero) and the weight gradient against torch on the unpadded
+    tensors."""
+    from mrfp_amd import conv
+    o = ops()
+    a, b = rnd(2, 48, 24, 16, seed=31), rnd(2, 256, 6, 4, seed=32)
+    w = rnd(64, 304, 3, 3, seed=33, scale=0.05)
+    if dtype != torch.float32:
+        a, b, w = a.to(dtype).float(), b.to(dtype).float(), w.to(dtype).float()
+    ac, bc, wc = a.clone().requires_grad_(True), b.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yc = F.conv2d(torch.cat([ac, F.interpolate(bc, size=(24, 16), mode="bilinear", align_corners=True)], 1), wc, None, 1, 1)
+    gy = rnd(*yc.shape, seed=34)
+    if dtype != torch.float32:
+        gy = gy.to(dtype).float()
+    yc.backward(gy)
+    ad, bd = dev(a, dtype), dev(b, dtype)
+    wd = w.to(DEV).requires_grad_(True)
+    cat = o.concat_upsample(ad, bd, (24, 16), 64)
+    assert cat.shape[1] == 320 and float(cat.detach()[:, 304:].abs().max()) == 0.0
+    cat.retain_grad()
+    y = conv.conv2d(cat, wd, None, 1, 1, 1)
+    y.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    t = 1e-5 if dtype == torch.float32 else 1.5e-2
+    assert relerr(y, yc) < t and relerr(ad.grad, ac.grad) < t and relerr(bd.grad, bc.grad) < t and relerr(wd.grad, wc.grad) < 2 * t
+    assert tuple(wd.grad.shape) == (64, 304, 3, 3) and float(cat.grad[:, 304:].abs().max()) == 0.0
