@@ -61,12 +61,18 @@ cfg.MODEL.COMMUTE_O2 = __import__("os").environ.get("MRFP_COMMUTE_O2", "1") != "
 # K dimension is whole 128-byte tiles -- aligned / row-reuse convolution kernels instead of the per-thread tap tracking of the
 # unaligned ones.  1 = the reference's 304.
 cfg.MODEL.DECODER_PAD = int(__import__("os").environ.get("MRFP_DECODER_PAD", "64"))
+# BatchNorm statistics summed over all ranks of the default process group (reference config.py:92-93, torch.nn.SyncBatchNorm).
+# Off: with 16 images per GPU the per-replica statistics ARE the reference's single-GPU population.
+cfg.MODEL.SYNC_BN = False
 # directory searched for ImageNet checkpoints when pretrained=True (no network access here)
 cfg.MODEL.PRETRAINED_DIR = None
 
 
 def assert_and_infer_cfg(args=None, make_immutable=True, train_mode=True):
-    """reference config.py:95-128.  Both settings of `syncbn` map to the HIP BatchNorm: per-replica
-    statistics are the reference's single-GPU semantics."""
+    """reference config.py:95-128.  `args.syncbn` turns cfg.MODEL.SYNC_BN on (cross-rank statistics in the HIP BatchNorm, what
+    torch.nn.SyncBatchNorm does in the reference); without it the statistics are per replica -- the reference's single-GPU
+    semantics."""
+    if args is not None and getattr(args, "syncbn", False):
+        cfg.MODEL.SYNC_BN = True
     if make_immutable:
         cfg.immutable(True)

@@ -178,6 +178,35 @@ SIGN_MASK = [os.environ.get("MRFP_SIGN_MASK", "1") != "0"]     # residual BatchN
 GATED_SKIP = [os.environ.get("MRFP_GATED_SKIP", "1") != "0"]   # ... and the skip gradient gated by the consuming dgrad epilogue
 
 
+SYNC_BN_CALLS = [0]       # BatchNorm layers that exchanged their statistics across ranks (tests)
+
+
+def _sync_bn_group():
+    """The process group BatchNorm statistics are summed over, or None: cfg.MODEL.SYNC_BN (the reference's syncbn switch,
+    config.py:92-93: torch.nn.SyncBatchNorm) with more than one rank.  Off by default: 16 images per GPU is the reference's
+    own statistical population; it matters for per-GPU batches below that (configs[4]: 2 images)."""
+    import torch.distributed as dist
+    from .config import cfg
+    if not cfg.MODEL.SYNC_BN or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() < 2:
+        return None
+    return dist.group.WORLD
+
+
+def _allreduce_stats(ws, rows, C, count, group):
+    """Per-channel (sum, second sum) partial rows of THIS rank -> the same two sums over all ranks, as a 2-row workspace (fp32
+    high part + remainder of the fp64 totals, which the finalize kernels add in fp64) and the global element count.  A few KB:
+    torch ops + one all-reduce of 2 C + 1 doubles (torch.nn.SyncBatchNorm exchanges the same quantities)."""
+    import torch.distributed as dist
+    tot = torch.zeros(2 * C + 1, dtype=torch.float64, device=ws.device)
+    tot[:2 * C] = ws.view(rows, 2 * C).sum(0, dtype=torch.float64)
+    tot[2 * C] = float(count)
+    dist.all_reduce(tot, group=group)
+    hi = tot[:2 * C].float()
+    lo = (tot[:2 * C] - hi.double()).float()
+    SYNC_BN_CALLS[0] += 1
+    return torch.stack([hi, lo]).contiguous(), int(round(tot[2 * C].item()))
+
+
 class _BatchNormAct(torch.autograd.Function):
     """y = act(BN(resize(x)) + res).  reference: Norm2d/SyncBatchNorm on one process = F.batch_norm
     (mynn.py:19-25), Bottleneck tail (Resnet.py:202-225), HRFP stage (deepv3.py:320-327)."""
@@ -199,9 +228,16 @@ class _BatchNormAct(torch.autograd.Function):
             else:
                 nslab, ws = _stats_fwd(x, plan)
                 nb_ = B
-            call("mrfp_bn_finalize", ptr(ws), nb_, nslab, B * Ho * Wo, C, ptr(w32), ptr(b32), float(eps),
+            count = B * Ho * Wo
+            ctx.sync = _sync_bn_group()
+            if ctx.sync is not None:        # statistics over the batches of ALL ranks (one host synchronisation: the count)
+                ws, count = _allreduce_stats(ws, nb_ * nslab, C, count, ctx.sync)
+                nb_, nslab = 1, 2
+            ctx.count = count
+            call("mrfp_bn_finalize", ptr(ws), nb_, nslab, count, C, ptr(w32), ptr(b32), float(eps),
                  float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(A), ptr(S), stream())
         else:
+            ctx.sync, ctx.count = None, B * Ho * Wo
             call("mrfp_bn_eval_coef", C, ptr(w32), ptr(b32), ptr(running_mean), ptr(running_var), float(eps),
                  ptr(A), ptr(S), stream())
             if x.requires_grad or (weight is not None and weight.requires_grad):
@@ -251,6 +287,12 @@ class _BatchNormAct(torch.autograd.Function):
         sb = grad_sink(ctx.bparam) if ctx.needs_input_grad[2] else None
         call("mrfp_bn_bwd_finalize", ptr(ws), nb_, nslab, B * Ho * Wo, C, ptr(w32), ptr(mean), ptr(invstd),
              ptr(sw if sw is not None else dw), ptr(sb if sb is not None else db), ptr(P), ptr(Q), ptr(R), stream())
+        if ctx.sync is not None:
+            # cross-rank statistics: dweight / dbias above are this rank's LOCAL sums (the data-parallel exchange averages
+            # them, as with torch.nn.SyncBatchNorm); the input-gradient coefficients use the sums over ALL ranks
+            gws, _ = _allreduce_stats(ws, nb_ * nslab, C, 0, ctx.sync)
+            call("mrfp_bn_bwd_finalize", ptr(gws), 1, 2, ctx.count, C, ptr(w32), ptr(mean), ptr(invstd), None, None,
+                 ptr(P), ptr(Q), ptr(R), stream())
         if not ctx.training:
             # module in eval mode (running statistics are constants): the same dweight / dbias sums, but the input
             # gradient is just dy' * weight * invstd -- the batch-statistics terms Q, R vanish

@@ -199,7 +199,7 @@ def test_bench_two_ranks_end_to_end():
     assert len(lines) == 1                                      # ONE JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
-    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["cpu_baseline"] is None
+    assert out["value"] > 0 and out["roofline"]["achieved"] > 0 and out["cpu_baseline"] is None
     assert out["ranks_seen"] == 2
 
 
@@ -220,3 +220,84 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 4
     assert out["value"] > 0 and out["cpu_baseline"] is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cfg.MODEL.SYNC_BN (reference config.py:105-107: torch.nn.SyncBatchNorm when args.syncbn): BatchNorm statistics over the
+# batches of all ranks.  Two ranks with two images each against ONE process with the four images: forward output, running
+# statistics, input gradient; the weight / bias gradients are each rank's LOCAL sums (the data-parallel exchange averages
+# them), so they add up to the single-process gradient.  Also through a residual tail (sign-mask path) and a conv epilogue
+# that produced the statistics.
+# ---------------------------------------------------------------------------------------------------------------------
+def _syncbn_case(device, dtype=torch.float32):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 64, 10, 12, generator=g)
+    res = torch.randn(4, 64, 10, 12, generator=g)
+    gy = torch.randn(4, 64, 10, 12, generator=g)
+    w, b = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    cw = torch.randn(64, 64, 1, 1, generator=g) * 0.1
+    to = lambda t: t.to(device, dtype).contiguous(memory_format=torch.channels_last)
+    return to(x), to(res), to(gy), w.to(device), b.to(device), cw.to(device)
+
+
+def _syncbn_run(sl, sync):
+    sys.path.insert(0, ROOT)
+    from mrfp_amd import conv, ops
+    from mrfp_amd.config import cfg
+    cfg.MODEL.SYNC_BN = sync
+    x, res, gy, w, b, cw = _syncbn_case("cuda:0")
+    out = {}
+    for name, use_res, through_conv in (("plain", False, False), ("res", True, False), ("conv", False, True)):
+        xs = x[sl].detach().clone().requires_grad_(True)
+        ws, bs = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rm, rv = torch.zeros(64, device="cuda:0"), torch.ones(64, device="cuda:0")
+        h = conv.conv2d(xs, cw, None, 1, 0, 1) if through_conv else xs       # (1x1 conv: its epilogue carries the statistics)
+        y = ops.batch_norm_act(h, ws, bs, rm, rv, training=True, relu=True, res=res[sl] if use_res else None)
+        y.backward(gy[sl])
+        out[name] = {k: v.detach().float().cpu() for k, v in (("y", y), ("dx", xs.grad), ("dw", ws.grad), ("db", bs.grad), ("rm", rm), ("rv", rv))}
+    cfg.MODEL.SYNC_BN = False
+    return out
+
+
+def _worker_syncbn(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from mrfp_amd import ops
+    before = ops.SYNC_BN_CALLS[0]
+    out = _syncbn_run(slice(2 * rank, 2 * rank + 2), True)
+    assert ops.SYNC_BN_CALLS[0] - before == 6          # forward + backward of the three layers
+    torch.save(out, os.path.join(outdir, "sbn%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
+    world, port = 2, 29761
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_syncbn, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    full = _syncbn_run(slice(0, 4), False)              # one process, all four images, no process group
+    parts = [torch.load(os.path.join(str(tmp_path), "sbn%d.pt" % r)) for r in range(world)]
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    for name in ("plain", "res", "conv"):
+        f = full[name]
+        for r in range(world):
+            sl = slice(2 * r, 2 * r + 2)
+            assert rel(parts[r][name]["y"], f["y"][sl]) < 2e-5, (name, r, "y")
+            assert rel(parts[r][name]["dx"], f["dx"][sl]) < 5e-5, (name, r, "dx")
+            assert rel(parts[r][name]["rm"], f["rm"]) < 1e-5 and rel(parts[r][name]["rv"], f["rv"]) < 1e-5, (name, r, "running")
+        assert rel(parts[0][name]["dw"] + parts[1][name]["dw"], f["dw"]) < 5e-5, (name, "dw")
+        assert rel(parts[0][name]["db"] + parts[1][name]["db"], f["db"]) < 5e-5, (name, "db")
+        # and per-replica statistics (the default) do NOT give the whole-batch result: the option changes something
+    sys.path.insert(0, ROOT)
+    local = _syncbn_run(slice(0, 2), False)
+    assert rel(local["plain"]["y"], full["plain"]["y"][0:2]) > 1e-3
