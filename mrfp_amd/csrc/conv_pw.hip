@@ -68,6 +68,26 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     if (t0 >= t1) return;
     const int n0 = panel * 128 + wave * 32;     // this wave's 32 columns
 
+    // ---- X tile DMA: piece q of this wave covers block kb = q / 2, rows (q & 1) * 32 + wave * 8 .. + 7 --------------------
+    unsigned src[NP], dst[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int kb = q >> 1, row = (q & 1) * 32 + wave * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);                     // source-side swizzle (LDS image is lane-linear)
+        src[q] = (unsigned)row * (unsigned)ROWB + (unsigned)(kb * 128 + ch * 16);
+        dst[q] = (unsigned)(kb * 64 * 128 + ((q & 1) * 32 + wave * 8) * 128);
+    }
+    auto issue = [&](int tile, int slot) {
+        const unsigned base = (unsigned)tile * 64u * (unsigned)ROWB;      // rows beyond M lie beyond xbytes: zero fill
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dma16_async(xw, lds0 + (unsigned)(slot * STAGE) + dst[q], base + src[q]);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (t0 + s < t1) issue(t0 + s, s);
+
+    // (The first transfers are issued BEFORE the weights are fetched: the weight prologue -- 16 loads per lane from L2, then a
+    //  full wait -- used to sit in front of them, ~1.4 us of a 27 us launch with nothing else in flight.)
     // ---- the weights: this wave's fragments for every K step, straight into registers ------------------------------------
     // The MFMA runs TRANSPOSED (D = W_tile * X_tile^T: accumulator rows = output channels, columns = pixels), so a lane
     // ends up with consecutive CHANNELS of one pixel and stores them directly -- no transposition of the result through
@@ -89,24 +109,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     for (int ks = 0; ks < KB * 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) settle(fw[ks][j]);
-
-    // ---- X tile DMA: piece q of this wave covers block kb = q / 2, rows (q & 1) * 32 + wave * 8 .. + 7 --------------------
-    unsigned src[NP], dst[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int kb = q >> 1, row = (q & 1) * 32 + wave * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);                     // source-side swizzle (LDS image is lane-linear)
-        src[q] = (unsigned)row * (unsigned)ROWB + (unsigned)(kb * 128 + ch * 16);
-        dst[q] = (unsigned)(kb * 64 * 128 + ((q & 1) * 32 + wave * 8) * 128);
-    }
-    auto issue = [&](int tile, int slot) {
-        const unsigned base = (unsigned)tile * 64u * (unsigned)ROWB;      // rows beyond M lie beyond xbytes: zero fill
-#pragma unroll
-        for (int q = 0; q < NP; ++q) dma16_async(xw, lds0 + (unsigned)(slot * STAGE) + dst[q], base + src[q]);
-    };
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (t0 + s < t1) issue(t0 + s, s);
 
     // (a half-tile start delay for the second resident workgroup of every CU was measured: no effect)
     const int nl = n0 + 8 * lq;                 // first of this lane's 8 output channels
