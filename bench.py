@@ -420,8 +420,9 @@ def measured_traffic(args):
     tools/measure_traffic.sh exactly as MI355X_MICROARCH.md prescribes, in their own rocprofv3 runs) -- read from the newest
     committed profiles/r*_traffic.json, which names the commit and the workload it was measured on.  Counters cannot be
     collected from inside this process.  The figure is reported as `traffic` only when that file describes THIS workload AND
-    the commit it was measured at is the running tree's; kernels may have changed since otherwise, and it goes under
-    `traffic_reference` with the commit next to it."""
+    the kernel sources are the ones it was measured on (`source_sha16` = mrfp_amd._lib.source_hash(): kernels, C header,
+    operator layer; or the same commit); kernels may have changed since otherwise, and it goes under `traffic_reference` with
+    the commit next to it."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files or args.fourier:
@@ -435,8 +436,10 @@ def measured_traffic(args):
     if (w.get("trunk"), w.get("size"), w.get("width"), w.get("batch"), w.get("dtype")) != \
             (args.trunk, args.size, args.width or args.size, args.batch, args.dtype):
         return {}
+    from mrfp_amd import _lib
     here = running_commit()
-    same = bool(here) and bool(t.get("commit")) and (here.startswith(t["commit"]) or t["commit"].startswith(here))
+    same = (t.get("source_sha16") == _lib.source_hash()) or \
+        (bool(here) and bool(t.get("commit")) and (here.startswith(t["commit"]) or t["commit"].startswith(here)))
     key = "traffic" if same else "traffic_reference"
     out = {}
     for fam in ("conv", "normalisation"):

@@ -102,6 +102,22 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources, the C header and the operator layer: what a measured figure (PMC traffic in
+    profiles/) is valid for.  Works without .git (the GPU box has none)."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = [HEADER] + [os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc")))
+                        if f.endswith((".hip", ".hpp"))]
+    files += [os.path.join(_HERE, f) for f in ("ops.py", "conv.py", "deepv3.py", "harness.py")]
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _FN = {}
 HOOK = [None]        # measurement only (bench.py): hook(name, args) runs right BEFORE the entry point is called
 

@@ -65,7 +65,9 @@ def main(out, steps_stats, steps_pmc):
                 per[family(r["Kernel_Name"])] = per.get(family(r["Kernel_Name"]), 0.0) + float(r["Counter_Value"]) * 1024.0 * corr
         res[tag] = {k: v / steps_pmc for k, v in per.items()}
     fams = sorted(set(res["read"]) | set(res["write"]))
-    traffic = {"commit": commit, "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/measure_traffic.sh; "
+    sys.path.insert(0, root)
+    from mrfp_amd import _lib
+    traffic = {"commit": commit, "source_sha16": _lib.source_hash(), "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/measure_traffic.sh; "
                "KB -> bytes, FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md)",
                "workload": {"trunk": "resnet-101", "size": 768, "width": 768, "batch": 16, "dtype": "bf16"},
                "steps_in_pmc_trace": steps_pmc,
