@@ -290,7 +290,9 @@ class Trainer:
         self.model = model
         self.opt = FlatSGD(model, lr, momentum, weight_decay, max_iter)
         self.sync = GradSync(self.opt, bucket_mb)
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        # (MRFP_FORCE_SYNC=1: the replica synchronisation -- parameter / buffer broadcasts, the shared toggle seed, the per-rank
+        #  torch seeds -- also runs at world size 1: the rehearsal of every collective of the multi-GPU path on one GPU over RCCL)
+        if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("MRFP_FORCE_SYNC") == "1"):
             sync_replicas(model, self.opt)
         if loss_scale is None:
             loss_scale = 65536.0 if cfg.MODEL.ACT_DTYPE == torch.float16 else 1.0

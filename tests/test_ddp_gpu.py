@@ -102,8 +102,15 @@ def _worker_nccl(outdir, force):
     sys.path.insert(0, ROOT)
     from mrfp_amd.harness import Trainer
     model = _Wrap(_build(0))
-    tr = Trainer(model, lr=1e-3, bucket_mb=4.0)
+    if force:
+        os.environ["MRFP_SEED"] = "1234"            # sync_replicas seeds the torch generators base + rank (rank 0: the base)
+    tr = Trainer(model, lr=1e-3, bucket_mb=4.0)       # force: sync_replicas runs its broadcasts over RCCL (world size 1)
     assert tr.sync.enabled == bool(force)
+    if force:
+        assert torch.initial_seed() == 1234
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)                         # bench.py's `ranks_seen`
+        assert int(ones.item()) == 1
     g = torch.Generator().manual_seed(100)
     x = (torch.rand(2, 3, 64, 64, generator=g) * 255).cuda()
     losses = [float(tr.step(x, None)) for _ in range(3)]
