@@ -1,0 +1,543 @@
+#include "conv_common.hpp"
+
+namespace mrfp {
+
+// =============================================================================================
+// B-stationary kernel for the short-K 1x1 convolutions (16-bit types, K = C <= 256, stride 1): Y[M, N] = X[M, K] W[N, K]^T.
+//
+// The generic kernel re-fetches a 128-column weight tile with every 96..192-row tile (55..77 FLOP per byte of L2 -> LDS
+// fill, the path that bounds it, profiles/r02_experiments.md), and with 2-4 K tiles per workgroup its prologue / epilogue
+// weigh as much as its K loop (M = 36 864, 256 -> 1024: 412 TFLOP/s).  Here a workgroup is PERSISTENT over a range of
+// 64-row M tiles of one 128-column panel:
+//   * the weights never touch LDS: each wave keeps its 32 columns x K of the panel as MFMA B fragments in REGISTERS
+//     (K = 256: 64 VGPRs), loaded once per workgroup;
+//   * only X moves: a 64 x K tile per step, asynchronous LDS-DMA into a ring (counted vmcnt, one barrier per tile, the
+//     transfer of tile t + NST - 1 issued before tile t is multiplied), i.e. 128 instead of 55..77 FLOP per fill byte;
+//   * the MFMA runs transposed (accumulator rows = channels), so every lane stores 8 consecutive channels of a pixel
+//     straight from its accumulators: no transposition through LDS, no epilogue barrier; the optional fused per-channel
+//     statistics and skip-gradient addend of the generic kernel are kept.
+// Two workgroups per CU interleave one's epilogue with the other's multiplies.
+// Layout of an X tile in LDS: KB blocks of [64 rows][128 bytes], each with the generic kernel's XOR swizzle, so the
+// fragment reads are the generic kernel's (bank-conflict free).
+// =============================================================================================
+
+struct BsP {
+    const char* x;       // [M][K] dense (K = C elements)
+    const char* w;       // forward pack [N][K]
+    char* y;             // [M][ldy]
+    const char* addend;  // [M][ldy] or null
+    const unsigned char* addend_mask;   // 1 bit per addend element or null (ConvP::addend_mask)
+    float* colstats;     // [ceil(M/64)][2][ldy] or null
+    int M, N, ldy;
+    int tiles;           // ceil(M / 64)
+    int panels;          // ceil(N / 128)
+    int chunks;          // M-tile ranges per panel (grid = panels * chunks)
+    unsigned xbytes, wbytes, ybytes;
+};
+
+struct HasPrev { static constexpr bool value = true; };
+struct NoPrev { static constexpr bool value = false; };
+template <typename T, int KB, int NST, bool STATS, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
+    constexpr int ROWB = KB * 128;              // bytes of one row of X (K elements)
+    constexpr int STAGE = KB * 64 * 128;        // one 64-row tile
+    constexpr int NP = KB * 2;                  // DMA pieces (8 rows x 128 B) per wave per tile: KB blocks x 8 pieces / 4 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: the DMA's LDS address (m0) must be uniform
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const i32x4 xw = rsrc_words(p.x, p.xbytes);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend ? p.addend : p.y), 0, (int)p.ybytes, 0x00020000);
+    // vmcnt bookkeeping: the output stores of a tile are issued AFTER the transfer of a later tile and are counted by the
+    // same in-order counter, so "tile t has landed" = all but the younger transfers AND the younger tiles' stores are
+    // done.  The stores are therefore UNCONDITIONAL buffer stores (rows / columns outside the tensor get an out-of-range
+    // offset and are dropped by the bounds check): exactly ST of them per wave per tile, whatever the tile covers.
+    constexpr int ST = 4;
+
+    // work: block b -> (chunk, panel) with the panels of one chunk (same rows of X) on one XCD (blocks b, b + 8, ... share an
+    // L2): b = xcd + 8 * (panel + panels * c2), chunk = xcd + 8 * c2
+    const int b = blockIdx.x, xcd = b & 7, rest = b >> 3;
+    const int panel = rest % p.panels, chunk = xcd + 8 * (rest / p.panels);
+    if (chunk >= p.chunks) return;              // (uniform per workgroup; no barrier has been passed yet)
+    const int per = (p.tiles + p.chunks - 1) / p.chunks;
+    const int t0 = chunk * per, t1 = min(p.tiles, t0 + per);
+    if (t0 >= t1) return;
+    const int n0 = panel * 128 + wave * 32;     // this wave's 32 columns
+
+    // ---- X tile DMA: piece q of this wave covers block kb = q / 2, rows (q & 1) * 32 + wave * 8 .. + 7 --------------------
+    unsigned src[NP], dst[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int kb = q >> 1, row = (q & 1) * 32 + wave * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);                     // source-side swizzle (LDS image is lane-linear)
+        src[q] = (unsigned)row * (unsigned)ROWB + (unsigned)(kb * 128 + ch * 16);
+        dst[q] = (unsigned)(kb * 64 * 128 + ((q & 1) * 32 + wave * 8) * 128);
+    }
+    auto issue = [&](int tile, int slot) {
+        const unsigned base = (unsigned)tile * 64u * (unsigned)ROWB;      // rows beyond M lie beyond xbytes: zero fill
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dma16_async(xw, lds0 + (unsigned)(slot * STAGE) + dst[q], base + src[q]);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (t0 + s < t1) issue(t0 + s, s);
+
+    // (The first transfers are issued BEFORE the weights are fetched: the weight prologue -- 16 loads per lane from L2, then a
+    //  full wait -- used to sit in front of them, ~1.4 us of a 27 us launch with nothing else in flight.)
+    // ---- the weights: this wave's fragments for every K step, straight into registers ------------------------------------
+    // The MFMA runs TRANSPOSED (D = W_tile * X_tile^T: accumulator rows = output channels, columns = pixels), so a lane
+    // ends up with consecutive CHANNELS of one pixel and stores them directly -- no transposition of the result through
+    // LDS, no 2-byte LDS stores, no epilogue barrier.  Accumulator row r = 4*(lane>>4) + e of channel block j is mapped to
+    // channel 8*(r>>2) + 4*j + (r&3) of the wave's 32 columns (a permutation of the weight rows, free at load time): a
+    // lane's 2 x 4 values are then channels 8*(lane>>4) .. +7 of its pixel = one 16-byte store.
+    uint4 fw[KB * 2][2];                        // [k step of 32][channel block]
+#pragma unroll
+    for (int ks = 0; ks < KB * 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 8 * (l15 >> 2) + 4 * j + (l15 & 3);           // the channel accumulator row l15 of block j stands for
+            fw[ks][j] = bload(wr, n < p.N ? (unsigned)n * (unsigned)ROWB + (unsigned)(ks * 64 + lq * 16) : kOOB);
+        }
+    // The weights must have ARRIVED before the tile loop: otherwise the compiler waits for them at their first use INSIDE the
+    // loop body, with `s_waitcnt vmcnt(15) ... vmcnt(0)` spread over the multiplies -- on every iteration, where they drain
+    // the transfers of the next tile and the stores of the previous one (seen in the ISA; it cost a third of the kernel).
+#pragma unroll
+    for (int ks = 0; ks < KB * 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) settle(fw[ks][j]);
+
+    // (a half-tile start delay for the second resident workgroup of every CU was measured: no effect)
+    const int nl = n0 + 8 * lq;                 // first of this lane's 8 output channels
+    float cs[8], cq[8];                         // per-channel sum / sum of squares over every tile of this workgroup
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { cs[u] = 0.f; cq[u] = 0.f; }
+
+    // SOFTWARE PIPELINE over the tiles: the epilogue of tile t-1 (conversions, statistics, addend, stores: ~150 vector
+    // instructions) is written BETWEEN the k steps of tile t, in one basic block with its multiplies (STATS / ADD are
+    // template parameters, so no branch splits the block): an MFMA holds the SIMD's vector issue for 8 of its 16 cycles, the
+    // other 8 take two ordinary instructions for free, so the epilogue rides in the multiply's issue shadow instead of
+    // running after it with the matrix pipe idle.  Two accumulator sets (A / B) alternate.
+    auto wait_tile = [&](int tile) {
+        // younger than the transfer of `tile` (issued in iteration tile-NST+1, before that iteration's body): the NST-2
+        // transfers of the tiles behind it and the stores issued in the bodies of iterations tile-NST+1 .. tile-1 -- which,
+        // one tile late in this pipeline, are those of tiles tile-NST .. tile-2: NST-1 batches, all of them real only from
+        // tile t0+NST on (the body of t0 has no epilogue in it; counting its absent stores let the second tile of a range be
+        // read before its last pieces had landed)
+        if (tile - t0 >= NST && tile + NST - 1 <= t1) dma_wait<(NST - 2) * NP + (NST - 1) * ST>();
+        else dma_wait<0>();                                               // first / last tiles of the range: fewer behind it
+        __builtin_amdgcn_s_barrier();                                     // tile landed everywhere; tile - 1 fully consumed
+    };
+    auto fetch_addend = [&](int tile, uint4 (&av)[4], unsigned (&am)[4]) {
+        // skip-gradient addend: fetched before the multiplies of its tile, consumed one tile later (a load issued in the
+        // epilogue would be waited for right there: 58 us against 32 us per dgrad launch).  Compiler-tracked on purpose: an
+        // untracked inline-asm load is WRONG here (the compiler may copy the destination registers before the data has
+        // arrived; the bitwise-reproducibility test caught it).
+        if constexpr (ADD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = tile * 64 + i * 16 + l15;
+                av[i] = bload(ar, (m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB);
+                // the gate bits of these 8 channels (all ones without a mask); a plain tracked load, issued with the addend
+                am[i] = (p.addend_mask && m < p.M && nl < p.N) ? p.addend_mask[((size_t)m * p.ldy + nl) >> 3] : 0xffu;
+            }
+        }
+    };
+    // one quarter (16 pixels) of the epilogue of `tile` from accumulator set acc
+    auto epilogue_part = [&](int tile, int i, const f32x4 (&acc)[4][2], const uint4 (&av)[4], const unsigned (&am)[4]) {
+        const int m = tile * 64 + i * 16 + l15;
+        const bool ok = m < p.M && nl < p.N;                              // (N % 8 == 0 for this kernel: chunks are whole)
+        uint4 v;
+        if constexpr (STATS) {
+            // Statistics of the fp32 accumulators (BEFORE the rounding to the 16-bit storage type): 8 v_add_f32 + 8 v_fma_f32 per 8
+            // outputs, SCALAR on purpose (packed v_pk_* fp32 arithmetic is an anti-lever beside MFMAs on gfx950:
+            // MI355X_MICROARCH.md).  Round 2 summed the stored (rounded) values -- 8 unpack + 8 multiply instructions more per 8
+            // outputs, and the compiler packed its adds into v_pk_add_f32 (profiles/r03_experiments.md).  The rounding errors are zero-mean and 2^-9
+            // relative: the batch mean / variance move by ~1e-5 of a standard deviation, below what bf16 activations resolve.
+            // Rows beyond M were zero-filled by the transfer's bounds check, so they add exactly 0: no mask.
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cs[u] += acc[i][0][u];
+                cs[4 + u] += acc[i][1][u];
+                cq[u] = __builtin_fmaf(acc[i][0][u], acc[i][0][u], cq[u]);
+                cq[4 + u] = __builtin_fmaf(acc[i][1][u], acc[i][1][u], cq[4 + u]);
+            }
+        }
+        if constexpr (ADD) {
+            // skip-gradient addend (gated in its packed form), added in fp32 BEFORE the one rounding to the storage type
+            const uint4 g = gate_chunk16(av[i], am[i]);
+            float a[8];
+            unpack2<T>(g.x, a[0], a[1]);
+            unpack2<T>(g.y, a[2], a[3]);
+            unpack2<T>(g.z, a[4], a[5]);
+            unpack2<T>(g.w, a[6], a[7]);
+            v.x = pack2<T>(acc[i][0][0] + a[0], acc[i][0][1] + a[1]);
+            v.y = pack2<T>(acc[i][0][2] + a[2], acc[i][0][3] + a[3]);
+            v.z = pack2<T>(acc[i][1][0] + a[4], acc[i][1][1] + a[5]);
+            v.w = pack2<T>(acc[i][1][2] + a[6], acc[i][1][3] + a[7]);
+        } else {
+            v.x = pack2<T>(acc[i][0][0], acc[i][0][1]);
+            v.y = pack2<T>(acc[i][0][2], acc[i][0][3]);
+            v.z = pack2<T>(acc[i][1][0], acc[i][1][1]);
+            v.w = pack2<T>(acc[i][1][2], acc[i][1][3]);
+        }
+        const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
+        u32x4 dv;
+        dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
+        __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)off, 0, 0);
+    };
+    // multiplies of `tile` into acc; when prev >= 0 the epilogue of tile `prev` (accumulators pacc, addend pav) in between
+    auto body = [&](int tile, f32x4 (&acc)[4][2], auto has_prev, const f32x4 (&pacc)[4][2], const uint4 (&pav)[4], const unsigned (&pam)[4]) {
+        const int prev = tile - 1;
+        const char* a = ring + ((tile - t0) % NST) * STAGE;
+        constexpr int KS = KB * 2;
+        // fragment reads run ONE K STEP AHEAD of the multiplies that use them (two register sets): left to itself the compiler
+        // issues each pair of reads two MFMAs before their use and waits for them (`s_waitcnt lgkmcnt(1)` after every
+        // second MFMA in the ISA), i.e. an LDS latency per 32 cycles of matrix work
+        uint4 fx[2][4];
+        auto read_x = [&](int ks, uint4 (&f)[4]) {
+            const char* ab = a + (ks >> 1) * (64 * 128);
+            const int ch = (ks & 1) * 4 + lq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const uint4*>(ab + lds_off(i * 16 + l15, ch));
+        };
+        read_x(0, fx[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) read_x(ks + 1, fx[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);    // (the scheduler otherwise sinks the reads back to just before their use)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (ks == 0) {                // first k step: accumulate onto a literal zero (no register clearing)
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        acc[i][j] = z;
+                    }
+                    Mma16<T>::run(acc[i][j], fw[ks][j], fx[ks & 1][i]);
+                }
+            if constexpr (decltype(has_prev)::value) {
+                // the 4 epilogue quarters of the previous tile, spread over the k steps
+                if constexpr (KS >= 4) { if (ks % (KS / 4) == 0) epilogue_part(prev, ks / (KS / 4), pacc, pav, pam); }
+                else { epilogue_part(prev, 2 * ks, pacc, pav, pam); epilogue_part(prev, 2 * ks + 1, pacc, pav, pam); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x4 accA[4][2], accB[4][2];
+    uint4 avA[4], avB[4];
+    unsigned amA[4] = {0xffu, 0xffu, 0xffu, 0xffu}, amB[4] = {0xffu, 0xffu, 0xffu, 0xffu};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { avA[i] = make_uint4(0u, 0u, 0u, 0u); avB[i] = make_uint4(0u, 0u, 0u, 0u); }
+    // first tile: multiplies only
+    wait_tile(t0);
+    fetch_addend(t0, avA, amA);
+    if (t0 + NST - 1 < t1) issue(t0 + NST - 1, (NST - 1) % NST);
+    body(t0, accA, NoPrev{}, accB, avB, amB);
+    int tile = t0 + 1;
+    for (; tile + 1 < t1; tile += 2) {
+        wait_tile(tile);
+        fetch_addend(tile, avB, amB);
+        if (tile + NST - 1 < t1) issue(tile + NST - 1, (tile - t0 + NST - 1) % NST);
+        body(tile, accB, HasPrev{}, accA, avA, amA);
+        wait_tile(tile + 1);
+        fetch_addend(tile + 1, avA, amA);
+        if (tile + NST < t1) issue(tile + NST, (tile + 1 - t0 + NST - 1) % NST);
+        body(tile + 1, accA, HasPrev{}, accB, avB, amB);
+    }
+    if (tile < t1) {                            // an even number of tiles: one more B step, then its own epilogue
+        wait_tile(tile);
+        fetch_addend(tile, avB, amB);
+        if (tile + NST - 1 < t1) issue(tile + NST - 1, (tile - t0 + NST - 1) % NST);
+        body(tile, accB, HasPrev{}, accA, avA, amA);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue_part(tile, i, accB, avB, amB);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue_part(t1 - 1, i, accA, avA, amA);
+    }
+    if constexpr (STATS) {
+        // ONE statistics row block per workgroup range (all its tiles): the 16 lanes of a quarter hold the same 8 channels
+        // for 16 different pixels -- fold them (DPP, fixed order) and let lane 0 of the quarter write
+        float* out = p.colstats + (size_t)chunk * 2 * p.ldy;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            cs[u] = row16_sum(cs[u]);
+            cq[u] = row16_sum(cq[u]);
+        }
+        if (l15 == 0 && nl < p.N) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                out[nl + u] = cs[u];
+                out[p.ldy + nl + u] = cq[u];
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// Round 3: the BARRIER-FREE form of the same convolution ("row kernel").  Every wave owns whole pixel rows:
+//   * the panel's weights sit in LDS (KB blocks of [128 channel rows][128 B], loaded and permuted once per workgroup);
+//   * a wave takes 32-pixel strips of the workgroup's range (strip s of the range goes to wave s mod 4: a fixed assignment, so
+//     the fused statistics are bitwise reproducible), fetches ITS X fragments straight from global memory into MFMA operand
+//     registers (lane = (pixel, 8 consecutive k): one 16-byte load per k step and 16-pixel block), multiplies them with the
+//     eight 16-channel weight blocks read from LDS, and stores 8 consecutive channels of a pixel per lane;
+//   * no LDS traffic for X, no transfer ring, no counted waits and NO workgroup barrier inside the loop: the four waves of a
+//     workgroup and the two workgroups of a CU run out of step and hide each other's load latency.
+// (The ring kernel above makes its four waves meet at a barrier per 64-row tile; with multiplies, fragment reads and epilogue
+//  compiled out that skeleton alone took 13.4 of its 27.4 us: profiles/r03_experiments.md section 1.)
+// =============================================================================================
+template <typename T, int KB, bool STATS, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv_pw_rows_kernel(BsP p) {
+    constexpr int KS = KB * 2;                  // k steps of 32
+    constexpr int ROWB = KB * 128;              // bytes of one row of X / of the weight pack
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend ? p.addend : p.y), 0, (int)p.ybytes, 0x00020000);
+
+    const int b = blockIdx.x, xcd = b & 7, rest = b >> 3;
+    const int panel = rest % p.panels, chunk = xcd + 8 * (rest / p.panels);
+    if (chunk >= p.chunks) return;              // (uniform per workgroup; no barrier has been passed yet)
+    const int per = (p.tiles + p.chunks - 1) / p.chunks;           // p.tiles = 32-row strips here
+    const int s0 = chunk * per, s1 = min(p.tiles, s0 + per);
+    if (s0 >= s1) return;
+    const int np0 = panel * 128;
+
+    // ---- the panel's weights -> LDS.  LDS row rho = 16 cb + r holds output channel 32 (cb >> 1) + 8 (r >> 2) + 4 (cb & 1) + (r & 3):
+    // accumulator row r = 4 lq + e of the two blocks of a pair then stands for the lane's channels 8 lq .. 8 lq + 7.
+    for (int e = t; e < KB * 1024; e += 256) {
+        const int kb = e >> 10, rem = e & 1023, rho = rem >> 3, ch = rem & 7;
+        const int cb = rho >> 4, r = rho & 15;
+        const int n = np0 + 32 * (cb >> 1) + 8 * (r >> 2) + 4 * (cb & 1) + (r & 3);
+        const uint4 v = bload(wr, n < p.N ? (unsigned)n * (unsigned)ROWB + (unsigned)(kb * 128 + ch * 16) : kOOB);
+        *reinterpret_cast<uint4*>(smem + kb * 16384 + lds_off(rho, ch)) = v;
+    }
+    __syncthreads();
+
+    float cs[STATS ? 32 : 1], cq[STATS ? 32 : 1];   // per-lane sums of its 4 x 8 channels over every strip of this wave
+    if constexpr (STATS) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { cs[u] = 0.f; cq[u] = 0.f; }
+    }
+    for (int s = s0 + wave; s < s1; s += 4) {
+        const int m0 = s * 32;
+        // this wave's X fragments for the whole strip (2 blocks of 16 pixels x KS k steps), and its addend chunks / gate bytes
+        uint4 fx[2][KS];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                fx[rb][ks] = bload(xr, (unsigned)(m0 + rb * 16 + l15) * (unsigned)ROWB + (unsigned)(ks * 64 + lq * 16));   // rows >= M: beyond xbytes, zeros
+        uint4 av[ADD ? 2 : 1][ADD ? 4 : 1];
+        unsigned am[ADD ? 2 : 1][ADD ? 4 : 1];
+        if constexpr (ADD) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int P = 0; P < 4; ++P) {
+                    const int m = m0 + rb * 16 + l15, n = np0 + 32 * P + 8 * lq;
+                    const bool ok = m < p.M && n < p.N;
+                    av[rb][P] = bload(ar, ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)n) * 2u : kOOB);
+                    am[rb][P] = (p.addend_mask && ok) ? p.addend_mask[((size_t)m * p.ldy + n) >> 3] : 0xffu;
+                }
+        }
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const char* wb = smem + (ks >> 1) * 16384;
+            const int ch = (ks & 1) * 4 + lq;
+            // weight fragments four blocks at a time, read one group ahead of the multiplies that use them (sched_barrier: left to
+            // itself the scheduler hoists all 64 reads of a strip -- 256 registers -- to the top)
+            uint4 wf[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wf[0][q] = *reinterpret_cast<const uint4*>(wb + lds_off(q * 16 + l15, ch));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wf[1][q] = *reinterpret_cast<const uint4*>(wb + lds_off((4 + q) * 16 + l15, ch));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const int cb = 4 * h + q;
+                        if (ks == 0) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[rb][cb] = z; }
+                        Mma16<T>::run(acc[rb][cb], wf[h][q], fx[rb][ks]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // epilogue: lane (l15, lq) holds channels np0 + 32 P + 8 lq .. + 7 of pixel m0 + 16 rb + l15
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int P = 0; P < 4; ++P) {
+                const f32x4 a0 = acc[rb][2 * P], a1 = acc[rb][2 * P + 1];
+                const int m = m0 + rb * 16 + l15, n = np0 + 32 * P + 8 * lq;
+                if constexpr (STATS) {      // of the fp32 accumulators; rows beyond M are zero (zero-filled X): no mask
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cs[8 * P + u] += a0[u];
+                        cs[8 * P + 4 + u] += a1[u];
+                        cq[8 * P + u] = __builtin_fmaf(a0[u], a0[u], cq[8 * P + u]);
+                        cq[8 * P + 4 + u] = __builtin_fmaf(a1[u], a1[u], cq[8 * P + 4 + u]);
+                    }
+                }
+                uint4 v;
+                if constexpr (ADD) {
+                    const uint4 g = gate_chunk16(av[rb][P], am[rb][P]);
+                    float a[8];
+                    unpack2<T>(g.x, a[0], a[1]);
+                    unpack2<T>(g.y, a[2], a[3]);
+                    unpack2<T>(g.z, a[4], a[5]);
+                    unpack2<T>(g.w, a[6], a[7]);
+                    v.x = pack2<T>(a0[0] + a[0], a0[1] + a[1]);
+                    v.y = pack2<T>(a0[2] + a[2], a0[3] + a[3]);
+                    v.z = pack2<T>(a1[0] + a[4], a1[1] + a[5]);
+                    v.w = pack2<T>(a1[2] + a[6], a1[3] + a[7]);
+                } else {
+                    v.x = pack2<T>(a0[0], a0[1]);
+                    v.y = pack2<T>(a0[2], a0[3]);
+                    v.z = pack2<T>(a1[0], a1[1]);
+                    v.w = pack2<T>(a1[2], a1[3]);
+                }
+                u32x4 dv;
+                dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
+                __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)((m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)n) * 2u : kOOB), 0, 0);
+            }
+    }
+    if constexpr (STATS) {
+        // fold the 16 pixel lanes of every channel (DPP, fixed order), then the four waves through LDS in wave order
+        __syncthreads();                                  // every wave is done reading the weights: LDS is reused
+        float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][128]
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const float a = row16_sum(cs[u]), q = row16_sum(cq[u]);
+            if (l15 == 0) {
+                const int c = 32 * (u >> 3) + 8 * lq + (u & 7);
+                red[(wave * 2 + 0) * 128 + c] = a;
+                red[(wave * 2 + 1) * 128 + c] = q;
+            }
+        }
+        __syncthreads();
+        const int st = t >> 7, c = t & 127;
+        const float v = (red[(0 * 2 + st) * 128 + c] + red[(1 * 2 + st) * 128 + c]) + (red[(2 * 2 + st) * 128 + c] + red[(3 * 2 + st) * 128 + c]);
+        if (np0 + c < p.N) p.colstats[(size_t)chunk * 2 * p.ldy + (size_t)st * p.ldy + np0 + c] = v;
+    }
+}
+
+static int g_bstat = -1;
+// the layers the B-stationary kernel takes (MRFP_CONV_PW=0: generic kernel everywhere, for A/B runs)
+static bool use_bstat(const ConvP& p, int esz) {
+    const bool has_bias = p.bias != nullptr;
+    if (g_bstat < 0) {
+        const char* e = getenv("MRFP_CONV_PW");
+        g_bstat = e ? atoi(e) : 1;
+    }
+    if (!g_bstat || esz != 2 || has_bias || (p.colstats && p.addend)) return false;
+    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.sstride != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
+    if (p.Ho != p.H || p.Wo != p.W || p.N < 128 || (p.N & 7) != 0) return false;
+    if ((int64_t)p.M * p.ldy * esz >= (int64_t)kOOB) return false;        // the output is addressed through a buffer descriptor
+    const int rowb = p.C * esz;
+    return rowb == 128 || rowb == 256 || rowb == 512;
+}
+
+static bool use_rows() { (void)g_bstat; return g_bstat >= 2; }     // MRFP_CONV_PW=2: the barrier-free row kernel
+
+// M-tile ranges per panel: two workgroups per CU, each at least 4 tiles long (the weights are loaded once per workgroup),
+// a multiple of 8 (the XCD mapping), and no range empty.  Also the number of statistics row blocks of such a launch.
+// (Row kernel: the units are 32-row strips, at least 8 per workgroup = two per wave.)
+static int bstat_chunks(int M, int N) {
+    const int tr = use_rows() ? 32 : 64, least = use_rows() ? 8 : 4;
+    const int tiles = (M + tr - 1) / tr, panels = (N + 127) / 128;
+    int chunks = 512 / panels;
+    while (chunks > 8 && (tiles + chunks - 1) / chunks < least) chunks -= 8;
+    chunks = (chunks + 7) / 8 * 8;
+    if (chunks < 8) chunks = 8;
+    const int per = (tiles + chunks - 1) / chunks;
+    return (tiles + per - 1) / per;              // ranges that actually hold tiles (the trailing ones would be empty)
+}
+
+template <typename T, int KB, bool STATS, bool ADD>
+static int launch_bstat(const ConvP& c, hipStream_t st) {
+    constexpr int NST = KB == 4 ? 2 : 3;                          // K = 256: 2 x 32 KB stages (two workgroups per CU)
+    constexpr int STAGE = KB * 64 * 128;
+    const int lds = NST * STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bstat_kernel<T, KB, NST, STATS, ADD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    BsP p;
+    p.x = c.x; p.w = c.w; p.y = c.y; p.addend = c.addend; p.addend_mask = c.addend_mask; p.colstats = c.colstats;
+    p.M = c.M; p.N = c.N; p.ldy = c.ldy;
+    p.tiles = (c.M + 63) / 64;
+    p.panels = (c.N + 127) / 128;
+    p.chunks = bstat_chunks(c.M, c.N);
+    const int chunks = (p.chunks + 7) / 8 * 8;           // grid: whole groups of 8 (workgroups past p.chunks exit at once)
+    p.xbytes = c.xbytes; p.wbytes = c.wbytes; p.ybytes = (unsigned)((int64_t)c.M * c.ldy * 2);
+    {   // timing-only diagnostics (MRFP_DEBUG_DROP bit 2: drop the output stores)
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
+        if (dbg & 4) p.ybytes = 0;
+    }
+    hipLaunchKernelGGL((conv1x1_bstat_kernel<T, KB, NST, STATS, ADD>), dim3((unsigned)(p.panels * chunks)), dim3(256), lds, st, p);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int KB, bool STATS, bool ADD>
+static int launch_rows(const ConvP& c, hipStream_t st) {
+    const int lds = KB * 16384;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_rows_kernel<T, KB, STATS, ADD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    BsP p;
+    p.x = c.x; p.w = c.w; p.y = c.y; p.addend = c.addend; p.addend_mask = c.addend_mask; p.colstats = c.colstats;
+    p.M = c.M; p.N = c.N; p.ldy = c.ldy;
+    p.tiles = (c.M + 31) / 32;                           // 32-row strips
+    p.panels = (c.N + 127) / 128;
+    p.chunks = bstat_chunks(c.M, c.N);
+    const int chunks = (p.chunks + 7) / 8 * 8;
+    p.xbytes = c.xbytes; p.wbytes = c.wbytes; p.ybytes = (unsigned)((int64_t)c.M * c.ldy * 2);
+    hipLaunchKernelGGL((conv_pw_rows_kernel<T, KB, STATS, ADD>), dim3((unsigned)(p.panels * chunks)), dim3(256), lds, st, p);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, bool STATS, bool ADD>
+static int run_bstat_v(const ConvP& p, hipStream_t st) {
+    const int kb = p.C * 2 / 128;
+    if (use_rows())
+        return kb == 1 ? launch_rows<T, 1, STATS, ADD>(p, st) : kb == 2 ? launch_rows<T, 2, STATS, ADD>(p, st) : launch_rows<T, 4, STATS, ADD>(p, st);
+    return kb == 1 ? launch_bstat<T, 1, STATS, ADD>(p, st) : kb == 2 ? launch_bstat<T, 2, STATS, ADD>(p, st) : launch_bstat<T, 4, STATS, ADD>(p, st);
+}
+template <typename T>
+static int run_bstat(const ConvP& p, hipStream_t st) {
+    // forward launches carry the fused statistics, dgrad launches the skip-gradient addend; never both in this network
+    if (p.colstats && p.addend) return -1;
+    if (p.colstats) return run_bstat_v<T, true, false>(p, st);
+    if (p.addend) return run_bstat_v<T, false, true>(p, st);
+    return run_bstat_v<T, false, false>(p, st);
+}
+
+bool pw_applicable(const ConvP& p, int esz) { return use_bstat(p, esz); }
+int64_t pw_stats_blocks(const ConvP& p) { return (int64_t)bstat_chunks(p.M, p.N); }
+int pw_run(const ConvP& p, bool is_f16, hipStream_t st) { return is_f16 ? run_bstat<f16>(p, st) : run_bstat<bf16>(p, st); }
+
+}  // namespace mrfp
