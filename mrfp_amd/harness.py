@@ -355,13 +355,16 @@ class Trainer:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):           # eager warm-up on a side stream (lazy tables, attributes, packs)
-                    loss = self._fwd_bwd(static_img, static_lab)
+                    loss = self._fwd_bwd(static_img, static_lab).detach()
                 torch.cuda.current_stream().wait_stream(side)
                 from . import conv
                 conv.join_wgrad_stream()
                 self.opt.step(1.0 / self.loss_scale)
+                # capture on the warm-up's stream, with the warm-up's autograd graph gone (.detach() above): a gradient
+                # accumulator that remembers another stream makes autograd fork / join the capture once per parameter, and
+                # the replay of such a graph pays a cross-queue barrier per fork (35 vs 15 ms on ResNet-50 8x512^2)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=side):
                     static_loss = self._fwd_bwd(static_img, static_lab)
             finally:
                 self.model.rng = rng
