@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay zero_grad + forward + backward as a hipGraph (single GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--dump-convs", default=None, help="write per-launch conv shapes/timings (JSON) here")
+    ap.add_argument("--dump-launches", default=None, help="diagnostic: time EVERY C-ABI launch of one step on its own, write JSON here")
     ap.add_argument("--fourier", action="store_true", help="variant: also attach the build-defined multi-resolution Fourier "
                     "amplitude perturbation (perturb.MultiResolutionFourier, every step) -- NOT the reference path, "
                     "reported as its own workload")
@@ -330,7 +331,7 @@ def step_roofline(model, trainer, x, y, args):
 
     def hook(name, a):
         fam = _family(name)
-        if fam == "conv" or fam != cur[0]:
+        if fam == "conv" or fam != cur[0] or args.dump_launches:
             e = timer.event()
             timer.record(e, st)
             marks.append([e, fam, []])
@@ -359,6 +360,16 @@ def step_roofline(model, trainer, x, y, args):
                 convs.append({"name": "mrfp_conv_fwd" if name == "mrfp_conv_fwd_gated" else name, "ms": ms, "flop": fl, "bytes": by,
                               "args": [int(d[k]) for k in _lib.ARG_NAMES[name][5:20]] if name != "mrfp_conv_wgrad"
                               else [int(d[k]) for k in _lib.ARG_NAMES[name][5:20]]})
+    if args.dump_launches:      # an event in front of EVERY launch (inflates the few-microsecond kernels: a diagnostic, not the bench line)
+        rows = []
+        for i, (e, fam, calls) in enumerate(marks):
+            ms = timer.elapsed_ms(e, marks[i + 1][0] if i + 1 < len(marks) else end)
+            name, d = calls[0]
+            fl, by = _launch_work(name, d, esz)
+            rows.append({"name": name, "family": fam, "ms": ms, "mbytes": by / 1e6, "gflop": fl / 1e9,
+                         "args": {k: (v if isinstance(v, (int, float)) and abs(v) < 10 ** 7 else bool(v)) for k, v in d.items()}})
+        with open(args.dump_launches, "w") as f:
+            json.dump(rows, f)
     tot_ms, tot_f = sum(c["ms"] for c in convs), sum(c["flop"] for c in convs)
     if args.dump_convs:
         with open(args.dump_convs, "w") as f:

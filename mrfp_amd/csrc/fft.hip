@@ -17,6 +17,7 @@
 //   pass 3  rows    S3              -> y  (Hermitian-extended inverse along W, real part, 1/(H*W))
 // Radix-2 / radix-3 Stockham autosort stages (lengths 2^a 3^b <= 512), twiddles from a host-built table.
 #include "common.hpp"
+#include <type_traits>
 
 namespace mrfp {
 
@@ -574,6 +575,197 @@ __global__ __launch_bounds__(kDirThreads) void dft_rows_inv_direct_kernel(FftP p
     }
 }
 
+// ---- band-limited inverse row pass on the MATRIX CORES (bf16 activations) -------------------------------------------
+// The direct sum above is  y[w][c] = x[w][c] + sum_k T[w][k] G[k][c]  with k = (bin, re / im) < 2 Ws: per image line a
+// [W x 2 Ws] x [2 Ws x C] matrix product.  As fp32 vector arithmetic it bounds the pass (profiles/r03_fourier.md: 39 us of
+// pure VALU issue at 16 x 128 x 192 x 192); v_mfma_f32_16x16x16_bf16 does it in a fraction of the memory time.  Precision:
+// G (fp32, from S3) and the trigonometric matrix T are each split into bf16 hi + lo parts and three products (hi*hi, lo*hi,
+// hi*lo) are accumulated in fp32 -- 16 mantissa bits per factor, the dropped lo*lo term is 2^-18 relative.
+// Layout: the A operand is G with its 16 rows mapped to channels c0 + 8 (r / 4) + 4 t + r % 4 (t = 0, 1: two 16-row tiles
+// = 32 channels), the B operand is T^t for 16 pixels.  The accumulator lane (g, n) then holds pixel w0 + n, channels
+// c0 + 8 g .. + 7: one 16-byte access of x and of y per lane, 64-byte runs per pixel.  No LDS: G comes straight from S3
+// (8-byte loads, k-contiguous), T is built once per wave from the twiddle table and stays in registers (wave q owns the
+// pixel tiles q, q + 4, ...); a workgroup walks consecutive (line, 32-channel block) items.
+typedef __attribute__((ext_vector_type(4))) short bfx4;
+typedef __attribute__((ext_vector_type(4))) float fx4;
+typedef float __attribute__((ext_vector_type(2))) fx2;
+typedef __bf16 __attribute__((ext_vector_type(2))) bfx2_t;
+
+// (a, b) -> bf16 hi parts and bf16 lo parts (a - hi(a), b - hi(b)), each pair in one dword
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    fx2 v; v.x = a; v.y = b;
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bfx2_t));
+    fx2 r; r.x = a - __uint_as_float(hi << 16); r.y = b - __uint_as_float(hi & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bfx2_t));
+}
+__device__ __forceinline__ bfx4 as_bfx4(unsigned a, unsigned b) {
+    uint2 u = make_uint2(a, b);
+    return __builtin_bit_cast(bfx4, u);
+}
+
+static int fft_mfma() {          // MRFP_FFT_MFMA=0: band-limited inverse row pass as the fp32 direct sum (A/B)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRFP_FFT_MFMA"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int fft_mfma_wgs() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRFP_FFT_MFMA_WGS"); v = e ? atoi(e) : 768; if (v < 8) v = 8; }
+    return v;
+}
+
+// LDS image of T^t: for every (part hi / lo, k block kb, lane quarter g) an array over the pixels w of 8-byte entries
+// (k = 16 kb + 4 g .. + 3), each array W * 8 + 128 bytes long: a fragment read (16 consecutive pixels x 4 quarters) covers
+// 4 x 128 contiguous bytes that start 32 banks apart -- the two passes a 512-byte read needs anyway, no conflicts beyond.
+__host__ __device__ inline int trig_pitch(int W) { return W * 8 + 128; }
+
+constexpr int kInvThreads = 256;     // 4 waves share one trigonometric table (40 KB at W = 192): three workgroups per CU
+
+// An item is (image line, block of NH x 32 channels, segment of TU pixel tiles), one wave per item at a time.  NH = 2 wherever C
+// allows: the two 64-byte halves of every 128-byte line are then requested together (with 32-channel items they were touched
+// an item apart, ~8 us, by which time the line had left the caches: twice the x and y traffic, 99 us instead of the 71 the
+// bytes take).  ALL of an item's loads (the G values, then NH x TU 16-byte pieces of x per lane) are issued up front in
+// straight-line code behind a sched_barrier, so the compiler's counted s_waitcnt vmcnt(N) lets tile u start when ITS piece has
+// landed while the later pieces and the stores of the earlier tiles are still in flight.
+template <int KB, int TU, int NH>      // KB: 16-deep k blocks (2 Ws <= 16 KB); TU: pixel tiles per item; NH: 32-channel halves per item
+__global__ __launch_bounds__(kInvThreads) void dft_rows_inv_mfma_kernel(FftP p, int items, int ipw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int Ws = p.Ws, W = p.W, C = p.C, ncb = C / (32 * NH), nseg = (W >> 4) / TU;      // (host: TU divides the W / 16 pixel tiles)
+    const int pitch = trig_pitch(W);
+    // the twiddle table first (one coalesced read; the W-entry gather below would otherwise be rounds of dependent global loads)
+    float2* twl = reinterpret_cast<float2*>(smem + 2 * KB * 4 * pitch);
+    for (int e = threadIdx.x; e < W; e += kInvThreads) twl[e] = p.tw[e];
+    __syncthreads();
+    // entry (kb, q, w): k = 16 kb + 4 q + i  <->  bin 8 kb + 2 q + (i >> 1), (i & 1) ? -sin : cos, times g_k / (H W)
+    for (int e = threadIdx.x; e < KB * 4 * W; e += kInvThreads) {
+        const int w = e % W, kq = e / W, q = kq & 3, kb = kq >> 2;
+        float v[4];
+        int idx = ((8 * kb + 2 * q) * w) % W;                                // (kw w) mod W, then + w per bin
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kw = 8 * kb + 2 * q + (i >> 1);
+            if (i == 2) { idx += w; if (idx >= W) idx -= W; }
+            const float2 t = twl[idx];                                       // exp(-2 pi i kw w / W) = (cos, -sin)
+            v[i] = kw < Ws ? (kw == 0 ? 1.f : 2.f) * p.scale * ((i & 1) ? t.y : t.x) : 0.f;
+        }
+        unsigned h0, l0, h1, l1;
+        split2(v[0], v[1], h0, l0);
+        split2(v[2], v[3], h1, l1);
+        *reinterpret_cast<uint2*>(smem + kq * pitch + w * 8) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(smem + (KB * 4 + kq) * pitch + w * 8) = make_uint2(l0, l1);
+    }
+    __syncthreads();
+    const char* th = smem + g * pitch + r * 8;                              // + kb * 4 * pitch + wt * 128
+    const char* tl = th + KB * 4 * pitch;
+    const int wid = blockIdx.x * (kInvThreads / 64) + wave;
+    const int it0 = wid * ipw, it1 = it0 + ipw < items ? it0 + ipw : items;
+    const char* xb = reinterpret_cast<const char*>(p.x);
+    char* yb = reinterpret_cast<char*>(p.y);
+    const size_t tstep = (size_t)16 * C * 2;                                 // bytes from a pixel tile to the next
+    constexpr int NT = 2 * NH;                                               // 16-row A tiles: channels c0 + 32 (t >> 1) + 8 (row / 4) + 4 (t & 1) + row % 4
+    for (int it = it0; it < it1; ++it) {
+        const int seg = it % nseg, lc = it / nseg, line = lc / ncb, c0 = (lc - line * ncb) * (32 * NH), wt0 = seg * TU;
+        const float2* s3 = p.S3 + (size_t)line * Ws * C + c0 + 8 * (r >> 2) + (r & 3);
+        float2 graw[NT][KB][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int k0 = 8 * kb + 2 * g;
+                const int ka = k0 < Ws ? k0 : Ws - 1, kc = k0 + 1 < Ws ? k0 + 1 : Ws - 1;   // past the band: any finite value (T is 0 there)
+                graw[t][kb][0] = s3[(size_t)ka * C + 32 * (t >> 1) + 4 * (t & 1)];
+                graw[t][kb][1] = s3[(size_t)kc * C + 32 * (t >> 1) + 4 * (t & 1)];
+            }
+        const size_t pix0 = (((size_t)line * W + wt0 * 16 + r) * C + c0 + 8 * g) * 2;      // this lane's pixel of the segment's first tile
+        uint4 xr[TU][NH];
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) xr[u][hh] = *reinterpret_cast<const uint4*>(xb + pix0 + (size_t)u * tstep + 64 * hh);
+        __builtin_amdgcn_sched_barrier(0);        // every load of the item is in flight before anything is consumed (the scheduler sinks them otherwise)
+        bfx4 ah[NT][KB], al[NT][KB];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                unsigned h0, l0, h1, l1;
+                split2(graw[t][kb][0].x, graw[t][kb][0].y, h0, l0);
+                split2(graw[t][kb][1].x, graw[t][kb][1].y, h1, l1);
+                ah[t][kb] = as_bfx4(h0, h1);
+                al[t][kb] = as_bfx4(l0, l1);
+            }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int wt = wt0 + u;
+            bfx4 bh[KB], bl[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                bh[kb] = *reinterpret_cast<const bfx4*>(th + kb * 4 * pitch + wt * 128);
+                bl[kb] = *reinterpret_cast<const bfx4*>(tl + kb * 4 * pitch + wt * 128);
+            }
+            fx4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = fx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[t][kb], bh[kb], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[t][kb], bl[kb], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[t][kb], bh[kb], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                const unsigned xin[4] = {xr[u][hh].x, xr[u][hh].y, xr[u][hh].z, xr[u][hh].w};
+                unsigned o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                              // channels c0 + 32 hh + 8 g + 2 q, + 1
+                    const float a = __uint_as_float(xin[q] << 16) + acc[2 * hh + (q >> 1)][(2 * q) & 3];
+                    const float b = __uint_as_float(xin[q] & 0xffff0000u) + acc[2 * hh + (q >> 1)][((2 * q) & 3) + 1];
+                    fx2 v; v.x = a; v.y = b;
+                    o[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bfx2_t));
+                }
+                *reinterpret_cast<uint4*>(yb + pix0 + (size_t)u * tstep + 64 * hh) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);    // tile by tile: multiply, add, store (not all stores at the end)
+        }
+    }
+}
+
+template <int KB, int TU, int NH>
+static int launch_inv_mfma_tu(const FftP& p, hipStream_t st) {
+    constexpr int WPG = kInvThreads / 64;
+    const int items = p.B * p.H * (p.C / (32 * NH)) * ((p.W >> 4) / TU);
+    int waves = fft_mfma_wgs() * WPG;
+    if (waves > items) waves = items;
+    const int ipw = (items + waves - 1) / waves;
+    const int grid = ((items + ipw - 1) / ipw + WPG - 1) / WPG;
+    const int lds = 2 * KB * 4 * trig_pitch(p.W) + p.W * (int)sizeof(float2);
+    auto kern = &dft_rows_inv_mfma_kernel<KB, TU, NH>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kInvThreads), lds, st, p, items, ipw);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+template <int KB>
+static int launch_inv_mfma(const FftP& p, hipStream_t st) {
+    const int ntile = p.W >> 4;          // pixel tiles per line; an item takes TU of them, TU | ntile (no predicated tile: every
+    if (p.C % 64 == 0) {                 // load and store of an item is straight-line code)
+        if (ntile % 6 == 0) return launch_inv_mfma_tu<KB, 6, 2>(p, st);
+        if (ntile % 4 == 0) return launch_inv_mfma_tu<KB, 4, 2>(p, st);
+        if (ntile % 3 == 0) return launch_inv_mfma_tu<KB, 3, 2>(p, st);
+        if (ntile % 2 == 0) return launch_inv_mfma_tu<KB, 2, 2>(p, st);
+        return launch_inv_mfma_tu<KB, 1, 2>(p, st);
+    }
+    if (ntile % 6 == 0) return launch_inv_mfma_tu<KB, 6, 1>(p, st);
+    if (ntile % 4 == 0) return launch_inv_mfma_tu<KB, 4, 1>(p, st);
+    if (ntile % 3 == 0) return launch_inv_mfma_tu<KB, 3, 1>(p, st);
+    if (ntile % 2 == 0) return launch_inv_mfma_tu<KB, 2, 1>(p, st);
+    return launch_inv_mfma_tu<KB, 1, 1>(p, st);
+}
+
 template <int N1, int N2>
 __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -664,6 +856,12 @@ static int launch_fast_pass(FftP p, int pass, const float2* tw, hipStream_t st) 
     using TS = TwoStep<N1, N2>;
     p.N = TS::N;
     p.tw = tw;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (p.delta && pass == 2 && p.C % 32 == 0 && p.W % 16 == 0 && 2 * p.Ws <= 48 && fft_mfma() && !fft_nodirect()) {
+            const int kb = (2 * p.Ws + 15) / 16;                // band-limited inverse row pass on the matrix cores
+            return kb == 1 ? launch_inv_mfma<1>(p, st) : kb == 2 ? launch_inv_mfma<2>(p, st) : launch_inv_mfma<3>(p, st);
+        }
+    }
     if (p.delta && pass == 2 && p.C % kDirCh == 0 && p.Ws <= 64 && !fft_nopair() && !fft_nodirect()) {
         // band-limited inverse row pass as a direct trigonometric sum
         constexpr int PPT = 8 / (int)sizeof(T);            // 16-byte activation accesses
