@@ -16,6 +16,8 @@
 //   pass 2  columns S, S[perm], mix -> S3 (inverse along H, ratio computed or loaded, optionally stored)
 //   pass 3  rows    S3              -> y  (Hermitian-extended inverse along W, real part, 1/(H*W))
 // Radix-2 / radix-3 Stockham autosort stages (lengths 2^a 3^b <= 512), twiddles from a host-built table.
+// Low band, bf16 activations: the two ROW passes of the band-limited path are matrix products on the MFMA units
+// (dft_rows_fwd_mfma_kernel / dft_rows_inv_mfma_kernel below; MRFP_FFT_MFMA=0 switches back to the FFT / direct-sum passes).
 #include "common.hpp"
 #include <type_traits>
 
@@ -766,6 +768,152 @@ static int launch_inv_mfma(const FftP& p, hipStream_t st) {
     return launch_inv_mfma_tu<KB, 1, 1>(p, st);
 }
 
+// ---- band-limited forward row pass on the matrix cores (bf16 activations) --------------------------------------------
+// S[kw][c] = sum_w x[w][c] exp(-2 pi i kw w / W) for the Ws stored bins: a [2 Ws x W] x [W x C] product per image line, x exact in
+// bf16, the trigonometric matrix split into bf16 hi + lo parts (two products).  The contraction index w is the SLOW index of x
+// ([w][c], channels contiguous), so a line's 32-channel slice is staged in LDS as it lies in memory and the B fragments are formed
+// with the transposing read ds_read_b64_tr_b16 (as conv_wgrad.hip does); the A fragments come from a table in LDS that is built
+// once per workgroup in fragment order (lane-linear 512-byte reads).  One wave per (line, 32-channel block) at a time, the waves
+// of a workgroup on neighbouring blocks of the same line; the next item's x is already on its way (in registers) while the
+// current one is multiplied out of LDS.
+constexpr int kFwdThreads = 512;                          // 8 waves
+typedef __attribute__((address_space(3))) bfx4 lds_bfx4;
+
+// the 16-byte pieces of one LDS segment of an item (image line, 32-channel block): lane (g, r) takes pixel r of every tile, chunk g
+template <int TU>
+__device__ __forceinline__ void fwd_issue(uint4 (&xr)[TU], const char* xb, int it, int seg, int ncb, int W, int C, int r, int g) {
+    const int line = it / ncb, c0 = (it - line * ncb) << 5;
+    const size_t pix0 = (((size_t)line * W + seg * TU * 16 + r) * C + c0 + 8 * g) * 2;
+    const size_t tstep = (size_t)16 * C * 2;
+#pragma unroll
+    for (int u = 0; u < TU; ++u) xr[u] = *reinterpret_cast<const uint4*>(xb + pix0 + (size_t)u * tstep);
+}
+
+template <int KB, int TU>      // TU: pixel tiles (of 16) per LDS segment of a line, TU | W / 16 (no predicated piece: the register array stays in registers)
+__global__ __launch_bounds__(kFwdThreads) void dft_rows_fwd_mfma_kernel(FftP p, int items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = kFwdThreads / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int Ws = p.Ws, W = p.W, C = p.C, ncb = C >> 5, ntile = W >> 4;
+    // A table: [part hi / lo][kb][ks] fragments of 64 lanes x 8 bytes; lane (r, q): k row 16 kb + r = (bin 8 kb + (r >> 1), re / im),
+    // pixels 16 ks + 4 q + i
+    float2* twl = reinterpret_cast<float2*>(smem + 2 * KB * ntile * 512 + NW * TU * 16 * 64);
+    for (int e = threadIdx.x; e < W; e += kFwdThreads) twl[e] = p.tw[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < KB * ntile * 64; e += kFwdThreads) {
+        const int l = e & 63, f = e >> 6, ks = f % ntile, kb = f / ntile;
+        const int kw = 8 * kb + ((l & 15) >> 1), ri = l & 1, w0 = 16 * ks + 4 * (l >> 4);
+        float v[4];
+        int idx = (kw * w0) % W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 t = twl[idx];                                       // exp(-2 pi i kw w / W) = (cos, -sin)
+            v[i] = kw < Ws ? (ri ? t.y : t.x) : 0.f;
+            idx += kw; if (idx >= W) idx -= W;
+        }
+        unsigned h0, l0, h1, l1;
+        split2(v[0], v[1], h0, l0);
+        split2(v[2], v[3], h1, l1);
+        *reinterpret_cast<uint2*>(smem + f * 512 + l * 8) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(smem + (KB * ntile + f) * 512 + l * 8) = make_uint2(l0, l1);
+    }
+    __syncthreads();
+    const char* ath = smem + lane * 8;                                      // + (kb * ntile + ks) * 512
+    const char* atl = ath + KB * ntile * 512;
+    char* xt = smem + 2 * KB * ntile * 512 + wave * (TU * 16 * 64);           // this wave's x segment: [pixel][64 bytes], chunk-swizzled
+    const int nwaves = gridDim.x * NW, wid = blockIdx.x * NW + wave;
+    const char* xb = reinterpret_cast<const char*>(p.x);
+    const int nseg = ntile / TU;
+    // the 16-byte chunk q of pixel row w sits at chunk q ^ (2 * ((w >> 2) & 1)): rows w and w + 4 (same banks otherwise) then use
+    // disjoint halves of their 64-byte row, and a transposed read (16 rows x 32 bytes) is the two passes its 512 bytes need anyway
+    const int wr_off = r * 64 + ((g ^ (((r >> 2) & 1) << 1)) << 4);           // store side: lane (g, r) holds pixel r of a tile, chunk g
+    // read side, B fragment of channel tile nt at k step ks: group g reads rows 16 ks + 4 g + (j >> 2), 4 channels at 4 (j & 3)
+    const int rd_row = 4 * g + (r >> 2);
+    const int rd_off0 = rd_row * 64 + (((0 + ((r & 3) >> 1)) ^ (((rd_row >> 2) & 1) << 1)) << 4) + 8 * (r & 1);
+    const int rd_off1 = rd_row * 64 + (((2 + ((r & 3) >> 1)) ^ (((rd_row >> 2) & 1) << 1)) << 4) + 8 * (r & 1);
+    int it = wid;
+    if (it >= items) return;                                                // (after the last barrier)
+    while (it < items) {
+        fx4 acc[KB][2];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) { acc[kb][0] = fx4{0.f, 0.f, 0.f, 0.f}; acc[kb][1] = fx4{0.f, 0.f, 0.f, 0.f}; }
+        for (int seg = 0; seg < nseg; ++seg) {
+            uint4 xr[TU];
+            // (a register set carried around the loop for the next item's pieces was demoted to scratch by the compiler; the eight waves
+            //  of the workgroup hide each other's load latency instead)
+            fwd_issue<TU>(xr, xb, it, seg, ncb, W, C, r, g);
+#pragma unroll
+            for (int u = 0; u < TU; ++u) *reinterpret_cast<uint4*>(xt + u * (16 * 64) + wr_off) = xr[u];
+#pragma unroll 2
+            for (int u = 0; u < TU; ++u) {
+                const int ks = seg * TU + u;
+                const bfx4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bfx4*)(xt + u * (16 * 64) + rd_off0));
+                const bfx4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bfx4*)(xt + u * (16 * 64) + rd_off1));
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const bfx4 ah = *reinterpret_cast<const bfx4*>(ath + (kb * ntile + ks) * 512);
+                    const bfx4 al = *reinterpret_cast<const bfx4*>(atl + (kb * ntile + ks) * 512);
+                    acc[kb][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, b0, acc[kb][0], 0, 0, 0);
+                    acc[kb][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, b1, acc[kb][1], 0, 0, 0);
+                    acc[kb][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, b0, acc[kb][0], 0, 0, 0);
+                    acc[kb][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, b1, acc[kb][1], 0, 0, 0);
+                }
+            }
+        }
+        // accumulator lane (g, n): k rows 16 kb + 4 g + i = bins 8 kb + 2 g (+1), (re, im); channel 16 nt + n
+        const int line = it / ncb, c0 = (it - line * ncb) << 5;
+        float2* dst = p.S + (size_t)line * Ws * C + c0 + r;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int kw = 8 * kb + 2 * g;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (kw < Ws) dst[(size_t)kw * C + 16 * nt] = make_float2(acc[kb][nt][0], acc[kb][nt][1]);
+                if (kw + 1 < Ws) dst[(size_t)(kw + 1) * C + 16 * nt] = make_float2(acc[kb][nt][2], acc[kb][nt][3]);
+            }
+        }
+        it += nwaves;
+    }
+}
+
+// LDS of the forward kernel with TU pixel tiles per segment: the A table (both parts, every k step), one x segment per wave, the twiddles
+static int fwd_lds_tu(int kb, int W, int tu) { return 2 * kb * (W >> 4) * 512 + (kFwdThreads / 64) * tu * 16 * 64 + W * (int)sizeof(float2); }
+// the largest segment that divides the line and fits the 160 KB of a CU next to the table (0: none)
+static int fwd_tu(int kb, int W) {
+    const int ntile = W >> 4;
+    for (int tu : {12, 8, 6, 4, 3, 2, 1})
+        if (ntile % tu == 0 && fwd_lds_tu(kb, W, tu) <= 160 * 1024) return tu;
+    return 0;
+}
+static int fwd_lds(int kb, int W) { return fwd_lds_tu(kb, W, fwd_tu(kb, W)); }
+
+template <int KB, int TU>
+static int launch_fwd_mfma_tu(const FftP& p, hipStream_t st) {
+    constexpr int NW = kFwdThreads / 64;
+    const int items = p.B * p.H * (p.C >> 5);
+    int grid = (items + NW - 1) / NW;
+    if (grid > 256) grid = 256;                                              // one workgroup per CU (LDS), persistent over its items
+    const int lds = fwd_lds(KB, p.W);
+    auto kern = &dft_rows_fwd_mfma_kernel<KB, TU>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kFwdThreads), lds, st, p, items);
+    MRFP_LAUNCH_CHECK();
+    return 0;
+}
+template <int KB>
+static int launch_fwd_mfma(const FftP& p, hipStream_t st) {
+    switch (fwd_tu(KB, p.W)) {
+        case 12: return launch_fwd_mfma_tu<KB, 12>(p, st);
+        case 8: return launch_fwd_mfma_tu<KB, 8>(p, st);
+        case 6: return launch_fwd_mfma_tu<KB, 6>(p, st);
+        case 4: return launch_fwd_mfma_tu<KB, 4>(p, st);
+        case 3: return launch_fwd_mfma_tu<KB, 3>(p, st);
+        case 2: return launch_fwd_mfma_tu<KB, 2>(p, st);
+    }
+    return launch_fwd_mfma_tu<KB, 1>(p, st);
+}
+
 template <int N1, int N2>
 __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -813,6 +961,20 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
         }
     }
     if (sub < N1) {
+        if (p.delta && p.ratio && 2 * p.Ws - 1 <= p.H) {
+            // band-limited path: the ratio differs from 1 only in the 2 M + 1 rows |kh| <= M = Ws - 1, and only those are kept
+            // ([B, 2 M + 1, Ws, C]: rows 0..M, then H-M..H-1) -- 1/6 of the bytes at H = 192, M = 16, in the forward and the backward call
+            const int M = p.Ws - 1;
+            float* rat = p.ratio + ((size_t)b * (2 * M + 1) * p.Ws + kw) * C + cg * kCB + ch;
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) {
+                const int kh = sub + N1 * k2;
+                const int cr = kh <= M ? kh : kh >= p.H - M ? kh - p.H + 2 * M + 1 : -1;
+                if (cr < 0) { if (p.load_ratio) rr[k2] = 1.f; continue; }
+                if (p.load_ratio) rr[k2] = rat[(size_t)cr * hs];
+                else rat[(size_t)cr * hs] = rr[k2];
+            }
+        } else {
         float* rat = p.ratio ? p.ratio + off : nullptr;
         if (p.load_ratio) {
 #pragma unroll
@@ -820,6 +982,7 @@ __global__ __launch_bounds__(two_nt(N1, N2)) void fft_cols_mix_kernel(FftP p) {
         } else if (rat) {
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) rat[(size_t)(sub + N1 * k2) * hs] = rr[k2];
+        }
         }
         const float one = p.delta ? 1.f : 0.f;                  // band-limited path: only the change F*(ratio-1) goes back
 #pragma unroll
@@ -857,6 +1020,11 @@ static int launch_fast_pass(FftP p, int pass, const float2* tw, hipStream_t st) 
     p.N = TS::N;
     p.tw = tw;
     if constexpr (std::is_same<T, bf16>::value) {
+        if (p.delta && pass == 0 && p.C % 32 == 0 && p.W % 16 == 0 && 2 * p.Ws <= 48 && fft_mfma() &&
+            fwd_tu((2 * p.Ws + 15) / 16, p.W) > 0) {
+            const int kb = (2 * p.Ws + 15) / 16;                // band-limited forward row pass on the matrix cores
+            return kb == 1 ? launch_fwd_mfma<1>(p, st) : kb == 2 ? launch_fwd_mfma<2>(p, st) : launch_fwd_mfma<3>(p, st);
+        }
         if (p.delta && pass == 2 && p.C % 32 == 0 && p.W % 16 == 0 && 2 * p.Ws <= 48 && fft_mfma() && !fft_nodirect()) {
             const int kb = (2 * p.Ws + 15) / 16;                // band-limited inverse row pass on the matrix cores
             return kb == 1 ? launch_inv_mfma<1>(p, st) : kb == 2 ? launch_inv_mfma<2>(p, st) : launch_inv_mfma<3>(p, st);

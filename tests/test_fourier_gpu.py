@@ -28,7 +28,11 @@ def relerr(a, b):
                                                    ((2, 16, 32, 48), 30.0, 1.0, False), ((2, 48, 128, 96), 24.0, 1.0, False),
                                                    # 64-channel tiles: inverse row pass as a direct trigonometric sum
                                                    ((2, 64, 96, 192), 16.0, 1.0, False), ((2, 128, 64, 128), 5.5, 0.7, False),
-                                                   ((1, 64, 32, 48), 3.0, 1.0, False), ((2, 64, 48, 32), 0.0, 1.0, False)])
+                                                   ((1, 64, 32, 48), 3.0, 1.0, False), ((2, 64, 48, 32), 0.0, 1.0, False),
+                                                   # bf16: band-limited row passes on the matrix cores -- two k blocks (9..16 stored
+                                                   # bins), 32-channel items (C % 64 != 0), a line longer than one LDS segment
+                                                   ((2, 64, 64, 96), 10.0, 1.0, False), ((2, 96, 96, 96), 12.0, 0.5, False),
+                                                   ((1, 32, 48, 384), 16.0, 1.0, False)])
 def test_fourier_amplitude_mix(dtype, shape, radius, lam, high):
     from mrfp_amd import ops
     B, C, H, W = shape
@@ -47,6 +51,32 @@ def test_fourier_amplitude_mix(dtype, shape, radius, lam, high):
     tol = 2e-5 if dtype == torch.float32 else 1.5e-2
     assert relerr(yd, yc) < tol
     assert relerr(xd.grad, xc.grad) < tol
+
+
+@pytest.mark.parametrize("shape,radius", [((4, 128, 96, 192), 16.0), ((2, 64, 64, 96), 10.0), ((2, 32, 48, 64), 5.0), ((2, 64, 32, 384), 16.0)])
+def test_bf16_matrix_core_row_passes_stay_within_two_output_ulps(shape, radius):
+    """The bf16 band-limited path forms its row sums with MFMA products of split-bf16 factors (csrc/fft.hip).  Against the fp32
+    definition evaluated with torch.fft on the SAME bf16 input: every output within 2.5 ulps of ITS OWN magnitude (bf16: 2^-8
+    relative), more than 99 % of them the correctly rounded value -- what the fp32 direct-sum path delivers (tools/fourier_ab.py
+    prints both; the loose norm-relative bound of the parametrised test above would not see a lost low-order part)."""
+    from mrfp_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(7 * H + W)
+    x = (torch.randn(*shape, generator=g) * 3 + 1).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    perm = torch.roll(torch.arange(B), 1)
+    y = ops.fourier_amplitude_mix(x, perm, radius, 1.0, False)
+    xf = x.float()
+    F = torch.fft.rfft2(xf)
+    A = F.abs()
+    kh = torch.arange(H, device=DEV)
+    dh = torch.minimum(kh, H - kh).float()
+    kw = torch.arange(W // 2 + 1, device=DEV).float()
+    band = (dh[:, None] ** 2 + kw[None, :] ** 2) <= radius * radius
+    rat = torch.where(band[None, None] & (A > 1e-20), A[perm.to(DEV)] / A.clamp_min(1e-30), torch.ones_like(A))
+    ref = torch.fft.irfft2(F * rat, s=(H, W))
+    err = (y.float() - ref).abs() / (ref.abs().clamp_min(1e-2) * 2.0 ** -8)
+    assert err.max().item() < 2.5, err.max().item()
+    assert (y == ref.to(torch.bfloat16)).float().mean().item() > 0.99
 
 
 def test_identity_when_partner_is_self():
