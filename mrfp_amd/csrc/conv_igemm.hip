@@ -551,6 +551,9 @@ static bool use_tile96(const ConvP& p, int esz) {
     }
     if (!g_t96 || p.N <= 64) return false;
     if (g_t96 == 2) return true;      // A/B measurements: 96-row tile wherever it is legal
+    // strided dgrads (a stride-2 forward's input gradient): the 128x128 tile won all three layers of the bench step by 8-13 %
+    // (tools/tile_sweep.sh, round 3)
+    if (p.sstride > 1) return false;
     // rounds of resident workgroups: 3 per CU for the 128x128 tile (144-148 registers), 4 per CU for the 96x128 tile
     // (<= 120).  Measured in the bench workload (bench.py --dump-convs, MRFP_CONV_T96=0/1/2): the 96-row tile wins
     // when everything fits one round (M = 36 864 layers: +7..35 %) and on short-K (memory-bound) layers; long-K
@@ -573,6 +576,14 @@ static bool use_tile192(const ConvP& p, int esz) {
     }
     if (!g_t192 || esz != 2 || p.N <= 64) return false;
     if (g_t192 == 2) return true;        // A/B measurements: 192-row tile wherever it is legal
+    // Whole rounds: three workgroups of this tile fit a CU (768 slots), and a launch of exactly 1, 2 or 4 rounds keeps every CU
+    // equally busy to the end -- measured (tools/tile_sweep.sh, round 3) on every such layer of the bench step against the tile
+    // the rules below pick: 2048 -> 512 @48^2 1x1 -19 %, 128 -> 128 @96^2 3x3 -16 %, 512 -> 2048 -11 %, 512 -> 128 @96^2 -8 %,
+    // 512 -> 512 @48^2 3x3 d2 -6 %, the stride-2 downsample 1x1s -12..-14 %.  (Not the strided dgrads: +47 %; not unaligned C.)
+    {
+        const int64_t t192 = ((int64_t)(p.M + 191) / 192) * ((p.N + 127) / 128);
+        if (p.sstride == 1 && (p.cpr & 7) == 0 && p.M % 192 == 0 && t192 % 768 == 0 && t192 <= 3072) return true;
+    }
     if (use_tile96(p, esz)) return false;
     const int nkt = (p.kchunks + 7) >> 3;
     return nkt >= 9 && ((p.M + 191) / 192) * ((p.N + 127) / 128) >= 2048;
@@ -605,7 +616,9 @@ static int rr_tile(const ConvP& p, int esz) {
     // waste most of its last 128-column tile.  Lost: M = 36 864, 256 -> 256 (384 tiles: 825 vs 880 TFLOP/s against the 96x128
     // tile), C = 128 (862 vs 912), N = 304 (918 vs 977).  Mode 3 lifts these restrictions (A/B runs).
     const int64_t t192 = (int64_t)(p.M / 192) * ((p.N + 127) / 128);
-    const bool pays = p.C >= 256 && t192 >= 512 && ((p.N + 127) / 128) * 128 - p.N <= 64;
+    // (two of these workgroups fit a CU: a launch that is not whole rounds of 512 and short -- 512 -> 512 @48^2 d2, 768 tiles -- runs
+    //  better on the plain 192x128 tile, three per CU: 887 vs 930 us for the six launches of the bench step)
+    const bool pays = p.C >= 256 && t192 >= 512 && (t192 >= 2048 || t192 % 512 == 0) && ((p.N + 127) / 128) * 128 - p.N <= 64;
     if (fits(192) && (g_rr >= 3 || (pays && (g_rr >= 2 || use_tile192(p, esz))))) return 192;
     return 0;
 }
