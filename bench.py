@@ -211,10 +211,22 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    trace = os.environ.get("MRFP_BENCH_TRACE") == "1"      # diagnostic: device time of every step of the timed region (hipEvents, no host sync)
+    if trace:
+        tm, evs = HipTimer(), []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if trace:
+            evs.append(tm.event())
+            tm.record(evs[-1], torch.cuda.current_stream().cuda_stream)
         loss = trainer.step(x, y)
+    if trace:
+        evs.append(tm.event())
+        tm.record(evs[-1], torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    if trace and rank == 0:
+        print("[bench] per-step device ms: " + " ".join("%.1f" % tm.elapsed_ms(evs[i], evs[i + 1]) for i in range(len(evs) - 1)),
+              file=sys.stderr, flush=True)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
