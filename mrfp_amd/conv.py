@@ -424,6 +424,7 @@ def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] =
     y, skip = out if want_skip else (out, None)
     if skip is not None:
         skip._mrfp_skip_alias = True      # its gradient goes to this convolution's dgrad epilogue and nowhere else
+        skip._mrfp_uses = [0]             # operators that consumed the alias so far (ops._chk): a gated gradient needs exactly one
     if _LAST_STATS[0] is not None and (phys_out is not None or Nphys == N):
         y._mrfp_colstats = _LAST_STATS[0]        # consumed by ops.batch_norm_act (statistics pass skipped)
     _LAST_STATS[0] = None

@@ -61,6 +61,9 @@ def zeros_cl(B, C, H, W, dtype, device) -> torch.Tensor:
 def _chk(x: torch.Tensor, name="x") -> torch.Tensor:
     if not x.is_cuda:
         raise _lib.MrfpHipError("%s must live on the GPU (got %s): the HIP path has no CPU fallback" % (name, x.device))
+    uses = getattr(x, "_mrfp_uses", None)
+    if uses is not None:          # a convolution's skip alias (conv.conv2d(..., want_skip=True)): count the operators that consume it
+        uses[0] += 1
     if x.dim() != 4 or not x.is_contiguous(memory_format=CL):
         x = to_cl(x)
     return x
@@ -256,6 +259,10 @@ class _BatchNormAct(torch.autograd.Function):
         # convolution's dgrad epilogue only, which can apply the gate itself -- backward then hands it the incoming
         # gradient as it is, with the mask attached, instead of writing dy * [y > 0]
         ctx.gate_skip = bool(ctx.ymask and GATED_SKIP[0] and getattr(res, "_mrfp_skip_alias", False))
+        # ... provided this tail stays the alias's ONLY consumer: with a second one autograd sums the two gradients into a fresh,
+        # untagged tensor and the unmasked one would be used as if it were masked.  Every operator of this layer counts its use
+        # of the alias (_chk); the count is read in backward, when the whole forward has run.
+        ctx.alias_uses = getattr(res, "_mrfp_uses", None)
         if ctx.ymask:
             y = empty_cl(B, C, Ho, Wo, x.dtype, dev)
             mask = torch.empty(B * Ho * Wo * C // 8, dtype=torch.uint8, device=dev)
@@ -300,7 +307,7 @@ class _BatchNormAct(torch.autograd.Function):
             R.zero_()
         if ctx.ymask:
             dx = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
-            if ctx.gate_skip and ctx.needs_input_grad[5]:
+            if ctx.gate_skip and ctx.needs_input_grad[5] and ctx.alias_uses is not None and ctx.alias_uses[0] == 1:
                 dres = dy.view_as(dy)                  # unmasked; the consumer applies the mask (conv._Conv2d.backward / conv.ungate)
                 dres._mrfp_gate = (y, dres._version)
                 call("mrfp_affine_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(dx), None, dt(dy), B, Ho, Wo, C, ptr(P), ptr(Q), ptr(R), 0,

@@ -472,6 +472,23 @@ def test_gated_skip_gradient_equals_the_materialised_one():
         ref = t.permute(0, 2, 3, 1).reshape(-1, 8).float() * torch.stack([(bits >> i) & 1 for i in range(8)], 1).float()
         out = conv.ungate(t).permute(0, 2, 3, 1).reshape(-1, 8).float()
         assert torch.equal(out, ref)
+        # a skip alias with a SECOND consumer: autograd sums the two gradients into an untagged tensor, so the tail must fall back to
+        # the materialised masked gradient (the use count of the alias is read in backward) -- same gradients as with the gate off
+        from mrfp_amd.network.mynn import HipConv2d, HipBatchNorm2d
+        torch.manual_seed(5)
+        cv, bn = HipConv2d(64, 64, kernel_size=1, bias=False).to(DEV), HipBatchNorm2d(64).to(DEV)
+        xin = torch.randn(2, 64, 12, 12, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        res = []
+        for gated in (True, False):
+            o.GATED_SKIP[0] = gated
+            conv.GATED_SKIP_HITS[0] = 0
+            xi = xin.clone().requires_grad_(True)
+            c, alias = cv.forward_skip(xi)
+            out = bn.fused(c, relu=True, res=alias) + o.add(alias, alias)       # the alias feeds the tail AND another operator
+            out.float().pow(2).mean().backward()
+            res.append(xi.grad.clone())
+            assert conv.GATED_SKIP_HITS[0] == 0
+        assert torch.equal(res[0], res[1])
     finally:
         o.GATED_SKIP[0] = True
         cfg.MODEL.ACT_DTYPE = torch.float32
