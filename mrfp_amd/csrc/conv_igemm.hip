@@ -576,6 +576,7 @@ static bool use_tile192(const ConvP& p, int esz) {
     }
     if (!g_t192 || esz != 2 || p.N <= 64) return false;
     if (g_t192 == 2) return true;        // A/B measurements: 192-row tile wherever it is legal
+    if (p.sstride > 1) return false;     // strided dgrads: the 128x128 tile wins (-12 %: the strided 192x128 instance spills 48 bytes per lane)
     // Whole rounds: three workgroups of this tile fit a CU (768 slots), and a launch of exactly 1, 2 or 4 rounds keeps every CU
     // equally busy to the end -- measured (tools/tile_sweep.sh, round 3) on every such layer of the bench step against the tile
     // the rules below pick: 2048 -> 512 @48^2 1x1 -19 %, 128 -> 128 @96^2 3x3 -16 %, 512 -> 2048 -11 %, 512 -> 128 @96^2 -8 %,
