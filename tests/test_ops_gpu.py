@@ -302,7 +302,9 @@ def test_cpu_input_fails_loudly():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [((2, 19, 12, 10), (48, 40)), ((1, 19, 7, 9), (25, 33)), ((2, 19, 16, 16), (16, 16))])
+@pytest.mark.parametrize("case", [((2, 19, 12, 10), (48, 40)), ((1, 19, 7, 9), (25, 33)), ((2, 19, 16, 16), (16, 16)),
+                                  # rows longer than one 256-pixel segment of the row kernel; scale 1 (a segment then touches 257 source pixels)
+                                  ((1, 19, 20, 150), (40, 300)), ((1, 19, 5, 600), (5, 600)), ((2, 19, 3, 257), (7, 771))])
 def test_fused_upsample_cross_entropy(dtype, case):
     """upsample + CE fused (no full-resolution logits) == Upsample() then CrossEntropyLoss(255) on the CPU."""
     o = ops()
