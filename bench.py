@@ -135,25 +135,59 @@ def cpu_baseline(args, seconds):
                       "deliver per_pixel_scaled_value images/sec" % (n, args.trunk, B, S, S, args.size, width, scale)}
 
 
-def launch_ranks(args):
+def _free_port():
+    import socket
+    with socket.socket() as s:                       # a free port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def launch_ranks(args, script=None, argv=None):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves.  The reference's
     own launch is a single `python main.py` (reference main_script.sh:1, main.py:39-52), so nothing upstream supplies a
     launcher.  Runs BEFORE anything touches the GPU, as a CHILD process (never exec: a process that has initialised
-    HIP must not be replaced), relays the child's output (rank 0 prints the one JSON line) and returns its exit code."""
-    import socket
+    HIP must not be replaced), relays the child's output (rank 0 prints the one JSON line) and returns its exit code.
+    The rendezvous port is found by bind-and-release (torch.distributed.run has to bind it itself), which leaves a small
+    window for another process to take it: if the child dies with "address already in use" before any rank printed a
+    result, ONE more attempt is made, in a fresh child on a fresh port (MRFP_BENCH_PORT pins the port: no retry then)."""
     import subprocess
-    port = os.environ.get("MRFP_BENCH_PORT")
-    if port is None:
-        with socket.socket() as s:                       # a free port on the loopback interface
-            s.bind(("127.0.0.1", 0))
-            port = str(s.getsockname()[1])
+    import threading
+    script = script or os.path.abspath(__file__)
+    argv = sys.argv[1:] if argv is None else argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
-    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env, cwd=ROOT)
+    # N ranks share this machine's cores: each rank's host side is one Python thread enqueueing launches (+ the autograd thread)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(4, (os.cpu_count() or 4) // max(1, args.gpus)))))
+    fixed = os.environ.get("MRFP_BENCH_PORT")
+    rc = 1
+    for attempt in range(1 if fixed else 2):
+        port = fixed or _free_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, script] + list(argv)
+        print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        seen = {"inuse": False, "result": False}
+
+        def relay(src, dst, key):
+            for line in src:
+                if key == "err" and ("EADDRINUSE" in line or "ddress already in use" in line):
+                    seen["inuse"] = True
+                if key == "out" and line.startswith("{"):
+                    seen["result"] = True
+                dst.write(line)
+                dst.flush()
+        th = [threading.Thread(target=relay, args=(child.stdout, sys.stdout, "out"), daemon=True),
+              threading.Thread(target=relay, args=(child.stderr, sys.stderr, "err"), daemon=True)]
+        for t in th:
+            t.start()
+        rc = child.wait()
+        for t in th:
+            t.join(timeout=10)
+        if rc == 0 or not seen["inuse"] or seen["result"]:
+            break
+        print("[bench] rendezvous port %s was taken between probing and binding: one more attempt on a fresh port" % port,
+              file=sys.stderr, flush=True)
+    return rc
 
 
 def main():
@@ -296,7 +330,7 @@ def _eager_step(trainer, x, y):
 #     sizeof x (tensor operands the launch reads or writes), from the launch arguments.
 #   * with --fourier: the build-defined Fourier amplitude mix (3 planes per call: x, the partner, y).
 # ---------------------------------------------------------------------------------------------------------------------
-CONV_CALLS = ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad")
+CONV_CALLS = ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad", "mrfp_conv_wgrad_grouped")
 NORM_CALLS = ("mrfp_stats_fwd", "mrfp_stats_bwd", "mrfp_stats_bwd_mask", "mrfp_affine_fwd", "mrfp_affine_bwd",
               "mrfp_affine_fwd_relu_mask", "mrfp_affine_bwd_mask", "mrfp_bn_finalize", "mrfp_bn_bwd_finalize", "mrfp_in_finalize",
               "mrfp_in_bwd_finalize", "mrfp_np_finalize", "mrfp_np_bwd_finalize", "mrfp_mean_finalize", "mrfp_bn_eval_coef",
@@ -312,15 +346,19 @@ def _family(name):
 def _launch_work(name, d, esz):
     """(algorithmic FLOP, algorithmic bytes) of one launch from its named arguments."""
     if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated"):
+        # ALGORITHMIC work: the logical channel counts (the zero channels of a padded buffer -- network input 3 -> 8, decoder
+        # concatenation 304 -> 320 -- are not work); conv.py reports them through _lib.NOTE, absent = the physical counts
         M = d["B"] * d["Ho"] * d["Wo"]
-        flop = 2.0 * M * d["N"] * d["R"] * d["S"] * d["C"] / float(d["sstride"] * d["sstride"])
-        byts = esz * (d["B"] * d["H"] * d["W"] * d["C"] + M * d["N"] + d["N"] * d["R"] * d["S"] * d["C"]
-                      + (M * d["N"] if d.get("addend") else 0)) + (M * d["N"] / 8.0 if d.get("addend_mask") else 0)
+        C, N = d.get("Clog", d["C"]), d.get("Nlog", d["N"])
+        flop = 2.0 * M * N * d["R"] * d["S"] * C / float(d["sstride"] * d["sstride"])
+        byts = esz * (d["B"] * d["H"] * d["W"] * C + M * N + N * d["R"] * d["S"] * C
+                      + (M * N if d.get("addend") else 0)) + (M * N / 8.0 if d.get("addend_mask") else 0)
         return flop, byts
-    if name == "mrfp_conv_wgrad":
+    if name in ("mrfp_conv_wgrad", "mrfp_conv_wgrad_grouped"):
         M = d["B"] * d["Ho"] * d["Wo"]
-        return (2.0 * M * d["N"] * d["R"] * d["S"] * d["C"],
-                esz * (d["B"] * d["H"] * d["W"] * d["C"] + M * d["N"]) + 4.0 * d["N"] * d["R"] * d["S"] * d["Ctrue"])
+        g = d.get("count", 1)
+        return (g * 2.0 * M * d["N"] * d["R"] * d["S"] * d["Ctrue"],
+                g * (esz * (d["B"] * d["H"] * d["W"] * d["Ctrue"] + M * d["N"]) + 4.0 * d["N"] * d["R"] * d["S"] * d["Ctrue"]))
     if name == "mrfp_fourier_mix":
         return 0.0, 3.0 * esz * d["B"] * d["H"] * d["W"] * d["C"]
     if name in NORM_CALLS:
@@ -348,8 +386,13 @@ def step_roofline(model, trainer, x, y, args):
             timer.record(e, st)
             marks.append([e, fam, []])
             cur[0] = fam
-        marks[-1][2].append((name, dict(zip(_lib.ARG_NAMES[name], a))))
+        d = dict(zip(_lib.ARG_NAMES[name], a))
+        if fam == "conv" and _lib.NOTE[0] is not None and name != "mrfp_conv_wgrad_grouped" and name != "mrfp_conv_wgrad":
+            d["Clog"], d["Nlog"] = _lib.NOTE[0]
+        _lib.NOTE[0] = None
+        marks[-1][2].append((name, d))
     _lib.lib()
+    _lib.NOTE[0] = None
     _lib.HOOK[0] = hook
     try:
         _eager_step(trainer, x, y)
@@ -369,9 +412,10 @@ def step_roofline(model, trainer, x, y, args):
             fl, by = _launch_work(name, d, esz)
             fam_bytes[fam] = fam_bytes.get(fam, 0.0) + by
             if fam == "conv":
-                convs.append({"name": "mrfp_conv_fwd" if name == "mrfp_conv_fwd_gated" else name, "ms": ms, "flop": fl, "bytes": by,
-                              "args": [int(d[k]) for k in _lib.ARG_NAMES[name][5:20]] if name != "mrfp_conv_wgrad"
-                              else [int(d[k]) for k in _lib.ARG_NAMES[name][5:20]]})
+                wg = name in ("mrfp_conv_wgrad", "mrfp_conv_wgrad_grouped")
+                first = _lib.ARG_NAMES[name].index("B")
+                convs.append({"name": "mrfp_conv_wgrad" if wg else "mrfp_conv_fwd", "ms": ms, "flop": fl, "bytes": by,
+                              "group": int(d.get("count", 1)), "args": [int(d[k]) for k in _lib.ARG_NAMES[name][first:first + 15]]})
     if args.dump_launches:      # an event in front of EVERY launch (inflates the few-microsecond kernels: a diagnostic, not the bench line)
         rows = []
         for i, (e, fam, calls) in enumerate(marks):
@@ -385,10 +429,11 @@ def step_roofline(model, trainer, x, y, args):
     tot_ms, tot_f = sum(c["ms"] for c in convs), sum(c["flop"] for c in convs)
     if args.dump_convs:
         with open(args.dump_convs, "w") as f:
-            json.dump([{"name": c["name"], "args": c["args"], "ms": c["ms"], "gflop": c["flop"] / 1e9, "mbytes": c["bytes"] / 1e6,
+            json.dump([{"name": c["name"], "args": c["args"], "group": c["group"], "ms": c["ms"], "gflop": c["flop"] / 1e9, "mbytes": c["bytes"] / 1e6,
                         "tflops": c["flop"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0} for c in convs], f)
     ach = tot_f / (tot_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_pw*_kernel+conv_wgrad_kernel (all %d conv launches of one step)" % len(convs),
+    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv_pw*_kernel+conv_wgrad_kernel (all %d conv launches of one step, %d weight-gradient problems in them)"
+            % (len(convs), sum(c["group"] for c in convs if c["name"] == "mrfp_conv_wgrad")),
             "achieved": round(ach, 2), "peak": peak_f, "unit": "TFLOP/s", "frac": round(ach / peak_f, 4),
             "traffic": None, "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3)}
     # every conv launch against ITS OWN bound: max(FLOP / MFMA peak, algorithmic bytes / HBM peak)

@@ -264,6 +264,19 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
                     int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,
                     int64_t R, int64_t S, int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w,
                     int64_t dil, void* stream);
+/* GROUPED weight gradients: `count` (<= mrfp_conv_wgrad_group_max()) problems of ONE geometry -- the repeated blocks of a ResNet
+ * stage (reference network/Resnet.py:579-585 _make_layer builds blocks-1 identical Bottlenecks; autograd of Resnet.py:202-216
+ * produces their weight gradients one by one) -- in ONE launch + ONE slab reduction: count x the output tiles fill the chip with
+ * 2-3 K' splits per problem instead of 21-32.  xs / dys / dws: HOST arrays of `count` device pointers (x[g], dy[g] as in
+ * mrfp_conv_wgrad; dws[g] = that problem's OIHW fp32 gradient); ws: mrfp_conv_wgrad_grouped_ws_bytes(M, N, Q, count) bytes.
+ * Every problem's result equals a mrfp_conv_wgrad_grouped call of the same count (fixed summation order: bitwise reproducible);
+ * it differs from the single launch's only in the association of the K' splits.  Each activation must fit one 3.75 GB range. */
+int64_t mrfp_conv_wgrad_group_max(void);
+int64_t mrfp_conv_wgrad_grouped_ws_bytes(int64_t M, int64_t N, int64_t Q, int64_t count);
+int mrfp_conv_wgrad_grouped(const void* const* xs, const void* const* dys, float* const* dws, int64_t count, void* ws, int dtype,
+                            int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,
+                            int64_t R, int64_t S, int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w,
+                            int64_t dil, void* stream);
 int mrfp_nchw_to_nhwc_pad(const float* x, void* y, int dtype, int64_t B, int64_t C, int64_t H, int64_t W,
                           int64_t Cpad, void* stream);
 

@@ -120,6 +120,8 @@ def source_hash() -> str:
 
 _FN = {}
 HOOK = [None]        # measurement only (bench.py): hook(name, args) runs right BEFORE the entry point is called
+NOTE = [None]        # measurement only: what the caller knows beyond the C arguments of its NEXT call -- (logical input channels,
+                     # logical output channels) of a convolution launch over channel-padded buffers; read and cleared by the hook
 
 
 def call(name: str, *args):

@@ -74,8 +74,7 @@ def build_variant(name: str, units, flags) -> str:
         if s[:-4] in units:
             o = os.path.join(CSRC, "%s_%s.variant.o" % (s[:-4], name))
             src = os.path.join(CSRC, s)
-            deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-            if not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps):
+            if _stale(o, s):                     # same dependency list as the main build: the source, every .hpp, include/mrfp_hip.h
                 r = subprocess.run(["hipcc", *FLAGS, *flags, "-c", src, "-o", o], capture_output=True, text=True)
                 if r.returncode != 0:
                     raise RuntimeError("hipcc failed for %s (%s):\n%s\n%s" % (s, name, r.stdout, r.stderr))

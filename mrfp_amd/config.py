@@ -49,8 +49,6 @@ cfg.MODEL.BN = "hip-batchnorm"
 cfg.MODEL.BNFUNC = None
 # activation storage dtype of the HIP path: torch.float32 (parity runs) or torch.bfloat16 (bench)
 cfg.MODEL.ACT_DTYPE = torch.float32
-# the only convolution backend: hand-written MFMA implicit-GEMM kernels (kept as a key so old configs still load)
-cfg.MODEL.CONV_BACKEND = "hip"
 # training: fuse final bilinear upsample + cross entropy (the full-resolution logits are never written)
 cfg.MODEL.FUSE_UPSAMPLE_CE = True
 # MRFP+ head: evaluate final2(Upsample(dec1) + OCout_dec) as Upsample(final2(dec1)) + final2(OCout_dec) (a 1x1 conv

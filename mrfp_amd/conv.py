@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import CL, _chk, empty_cl, grad_sink, notify_grad, zeros_cl
+from .ops import CL, GRAD_DEFERRED, _chk, empty_cl, grad_sink, notify_grad, zeros_cl
 
 _PACKS = {}      # id(weight Parameter) -> {key: _Pack}; entry dropped when the Parameter dies
 import os as _os
@@ -82,12 +82,12 @@ def get_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, Cphys: i
 _BATCH = {}
 
 
-def _packable(pk, w):
-    return (w is not None and pk.bias is None and w.dtype == torch.float32 and w.is_contiguous()
+def _packable(pk, w, with_bias=False):
+    return (w is not None and (with_bias or pk.bias is None) and w.dtype == torch.float32 and w.is_contiguous()
             and w.shape[2] * w.shape[3] <= 9)        # the brick kernel holds up to 3x3 taps; the 7x7 stem packs lazily
 
 
-def _batched_repack(todo, tag):
+def _batched_repack(todo, tag, biases=None):
     """ONE mrfp_pack_weights_batched launch per dtype for the (key, pack, weight) triples in `todo`; the job table is cached
     per (tag, dtype) and rebuilt only when the set of packs changes."""
     import numpy as np
@@ -112,9 +112,13 @@ def _batched_repack(todo, tag):
                   "prefix": torch.from_numpy(prefix).to(dev), "total": int(prefix[-1]), "n": len(items)}
             _BATCH[(tag, dtype)] = st
         call("mrfp_pack_weights_batched", ptr(st["jobs"]), ptr(st["prefix"]), st["n"], st["total"], _lib._DT[dtype], stream())
-        if not torch.cuda.is_current_stream_capturing():
-            for key, pk, w in items:
-                pk.version = (w._version, 0, _EPOCH[0])
+        capturing = torch.cuda.is_current_stream_capturing()
+        for key, pk, w in items:
+            b = biases.get(id(w)) if biases else None
+            if b is not None and pk.bias is not None:           # packs with a bias (the HRFP convolutions): refresh the fp32 copy
+                pk.bias[:w.shape[0]].copy_(b.detach())
+            if not capturing:
+                pk.version = (w._version, b._version if b is not None else 0, _EPOCH[0])
 
 
 def repack_all():
@@ -133,17 +137,21 @@ def repack_all():
         _batched_repack(todo, "trainable")
 
 
-def repack_weights(weights, tag="list"):
+def repack_weights(weights, tag="list", biases=None):
     """The same for an explicit list of weights that were just rewritten (the HRFP branch's convolutions after their
     re-initialisation: reference deepv3.py:290-299 re-draws them at the start of a forward; 28 pack launches per step
-    otherwise).  Weights without a cached pack yet are left to the lazy path."""
+    otherwise).  `biases`: the bias Parameter of each weight (or None) -- a pack with a bias gets its fp32 copy refreshed here too.
+    Weights without a cached pack yet are left to the lazy path."""
     todo = []
+    bmap = {id(w): b for w, b in zip(weights, biases)} if biases is not None else {}
     for w in weights:
         for key, pk in _PACKS.get(id(w), {}).items():
-            if _packable(pk, w) and pk.wf is not None:
+            has_b = bmap.get(id(w)) is not None
+            if pk.wf is not None and _packable(pk, w, with_bias=has_b) and (pk.bias is None) == (not has_b) \
+                    and key[4] == (bmap[id(w)].data_ptr() if has_b else 0):
                 todo.append((key, pk, w))
     if todo:
-        _batched_repack(todo, tag)
+        _batched_repack(todo, tag, bmap)
 
 
 def _out_size(H, R, stride, pad, dil):
@@ -172,6 +180,10 @@ _JOIN_QUEUED = [False]
 
 def _join_at_end_of_backward():
     _JOIN_QUEUED[0] = False
+    flush_wgrads()
+    _WG_EXPECT.clear()
+    _WG_EXPECT.update(_WG_SEEN)
+    _WG_SEEN.clear()
     join_wgrad_stream()
 
 
@@ -184,6 +196,125 @@ def join_wgrad_stream(stream=None):
         tgt.wait_stream(st)
     if stream is None:
         _WGRAD_PENDING[0] = False
+
+
+# ---- grouped, deferred weight gradients ----------------------------------------------------------------------------
+# A ResNet stage is `blocks` Bottlenecks of ONE geometry (reference network/Resnet.py:579-585 _make_layer; autograd of
+# Resnet.py:202-216 yields their weight gradients one launch at a time).  At M = 16*48*48 a single launch has 16-72 output tiles
+# and needs 21-32 K' splits to fill 256 CUs -- 12 K' tiles per workgroup behind a prologue, and fp32 slabs of 20-30x the size of
+# dW written and read again.  Weight gradients feed nothing but the optimizer, so they can wait: with a gradient arena present
+# (harness.FlatArena) backward only QUEUES (x, dy, sink) per launch geometry and mrfp_conv_wgrad_grouped runs a whole queue as one
+# launch + one slab reduction -- when a queue is full, when backward leaves a stage (wgrad_boundary), and when backward ends.
+GROUP_WGRAD = [_os.environ.get("MRFP_WGRAD_GROUP", "1") != "0"]
+_WG_QUEUE = {}              # launch geometry -> [(x, dy, sink, weight)]
+_WG_PENDING_BYTES = [0]
+_WG_MAX_BYTES = int(float(_os.environ.get("MRFP_WGRAD_GROUP_GB", "24")) * (1 << 30))    # activations a queue may keep alive
+WGRAD_GROUP_LAUNCHES = []   # sizes of the grouped launches issued (tests / diagnostics; cleared by the reader)
+_GROUP_MAX = [None]
+# How many problems of a geometry one backward pass produces is learnt from the previous pass: a geometry that came ONCE is
+# launched at once from then on (nothing to group with -- and the last layers of backward, the stem, would otherwise leave as an
+# exposed tail behind the end of the dgrad chain), a repeated one leaves as soon as its expected count is complete.
+_WG_EXPECT = {}             # launch geometry -> problems seen in the last complete backward pass
+_WG_SEEN = {}               # ... in the running one
+
+
+def _issue_wgrads(sig, items):
+    """One mrfp_conv_wgrad(_grouped) launch for `items` (same geometry) on the weight-gradient stream (or the current one)."""
+    import ctypes
+    (dtype, B, H, W, Cphys, C, N, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil) = sig
+    x0 = items[0][0]
+    M, Q = B * Ho * Wo, R * S * Cphys
+    side = wgrad_stream(x0.device)
+    L = _lib.lib()
+
+    def run():
+        n = len(items)
+        if n == 1:
+            x, dy, sink, _ = items[0]
+            ws = torch.empty(int(L.mrfp_conv_wgrad_ws_bytes(M, N, Q)), dtype=torch.uint8, device=x.device)
+            call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(sink), ptr(ws), _lib._DT[dtype], B, H, W, Cphys, C, N, Nphys, R, S,
+                 Ho, Wo, stride, pad_h, pad_w, dil, stream())
+            return
+        ws = torch.empty(int(L.mrfp_conv_wgrad_grouped_ws_bytes(M, N, Q, n)), dtype=torch.uint8, device=x0.device)
+        arr = ctypes.c_void_p * n
+        xs, dys, dws = arr(*[ptr(i[0]) for i in items]), arr(*[ptr(i[1]) for i in items]), arr(*[ptr(i[2]) for i in items])
+        call("mrfp_conv_wgrad_grouped", xs, dys, dws, n, ptr(ws), _lib._DT[dtype], B, H, W, Cphys, C, N, Nphys, R, S,
+             Ho, Wo, stride, pad_h, pad_w, dil, stream())
+
+    if side is not None:
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            run()
+        for x, dy, _, _ in items:
+            dy.record_stream(side)
+            x.record_stream(side)
+        _WGRAD_PENDING[0] = True
+    else:
+        run()
+    WGRAD_GROUP_LAUNCHES.append(len(items))
+    for _, _, _, weight in items:
+        GRAD_DEFERRED.discard(id(weight))
+        notify_grad(weight)
+
+
+def flush_wgrads(sig=None):
+    """Issues the queued weight gradients (of one launch geometry, or all of them in first-queued order)."""
+    keys = [sig] if sig is not None else list(_WG_QUEUE.keys())
+    for k in keys:
+        items = _WG_QUEUE.pop(k, None)
+        if not items:
+            continue
+        _WG_PENDING_BYTES[0] -= sum(i[0].numel() * i[0].element_size() + i[1].numel() * i[1].element_size() for i in items)
+        _issue_wgrads(k, items)
+
+
+def _queue_wgrad(sig, x, dy, sink, weight):
+    if _GROUP_MAX[0] is None:
+        _GROUP_MAX[0] = int(_lib.lib().mrfp_conv_wgrad_group_max())
+    if not _JOIN_QUEUED[0]:       # when this backward pass ends: flush every queue, then the caller's stream waits for the side stream
+        _JOIN_QUEUED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_at_end_of_backward)
+    seen = _WG_SEEN[sig] = _WG_SEEN.get(sig, 0) + 1
+    expect = _WG_EXPECT.get(sig, 0)
+    if expect == 1 and seen == 1 and sig not in _WG_QUEUE:
+        _issue_wgrads(sig, [(x, dy, sink, weight)])       # a geometry of its own: nothing to wait for
+        return
+    q = _WG_QUEUE.setdefault(sig, [])
+    q.append((x, dy, sink, weight))
+    GRAD_DEFERRED.add(id(weight))
+    _WG_PENDING_BYTES[0] += x.numel() * x.element_size() + dy.numel() * dy.element_size()
+    if len(q) >= _GROUP_MAX[0] or (expect > 1 and seen % expect == 0):
+        flush_wgrads(sig)
+    elif _WG_PENDING_BYTES[0] > _WG_MAX_BYTES:
+        flush_wgrads()
+
+
+def _drop_stale_backward_state():
+    """A forward convolution while the end-of-backward callback is still marked as queued: the last backward pass died with an
+    exception before the engine ran its callbacks.  Forget its queued weight gradients (their step is lost anyway) so that the
+    next backward registers its own callback."""
+    _JOIN_QUEUED[0] = False
+    _WG_QUEUE.clear()
+    _WG_SEEN.clear()
+    _WG_EXPECT.clear()
+    _WG_PENDING_BYTES[0] = 0
+    GRAD_DEFERRED.clear()
+
+
+def wgrad_boundary(t):
+    """Marks a stage boundary on activation `t` (the input of a ResNet stage / of the head): when backward has produced t's
+    gradient, everything behind it has queued its weight gradients, and the queues are issued -- the stage's gradient buckets
+    complete there (harness.GradSync launches buckets in index order, so later arrival is tolerated) instead of at the very end
+    of backward.  Returns t."""
+    if GROUP_WGRAD[0] and t.requires_grad and torch.is_grad_enabled():
+        t.register_hook(_boundary_hook)
+    return t
+
+
+def _boundary_hook(_grad):
+    flush_wgrads()
+    return None
 
 
 GATED_SKIP_HITS = [0]       # dgrad launches that applied a residual tail's gate to their addend (tests)
@@ -203,6 +334,11 @@ def ungate(t):
     return out
 
 
+def L_single(B, H, W, Cphys, Ho, Wo, Nphys, esz):
+    """both operands of a weight-gradient problem fit one 3.75 GB buffer-descriptor range (a grouped launch needs that)"""
+    return max(B * H * W * Cphys, B * Ho * Wo * Nphys) * esz < 0xF0000000
+
+
 class _Conv2d(torch.autograd.Function):
     """want_skip: also return an alias of x for a skip connection; the gradient arriving on that alias is added by
     the dgrad kernel's epilogue (no separate accumulation pass over the activation)."""
@@ -220,6 +356,7 @@ class _Conv2d(torch.autograd.Function):
             # no bias = a convolution that feeds a normalisation layer: let the epilogue produce its statistics
             nblk = int(L.mrfp_conv_stats_blocks(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1))
             stats = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Nphys, dtype=torch.float32, device=x.device)
+        _lib.NOTE[0] = (C, N)
         call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
              Ho, Wo, stride, pad_h, pad_w, dil, 1, None, ptr(stats), stream())
         if stats is not None:      # the rows the BatchNorm finalize should read (compacted for large launches)
@@ -237,6 +374,16 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dskip=None):
         x, weight, bias = ctx.saved_tensors
+        cell = getattr(ctx, "_mrfp_cell", None)
+        if cell is not None and cell[1]:
+            # a residual tail handed its UNMASKED incoming gradient to this alias (ops._BatchNormAct.backward): only the tagged
+            # tensor itself may arrive here.  Anything else means a consumer the use count did not see (a raw torch op on the
+            # alias) made autograd sum gradients into an untagged tensor -- fail loudly, the sum would be silently wrong
+            g = getattr(dskip, "_mrfp_gate", None) if dskip is not None else None
+            if g is None or g[1] != dskip._version:
+                raise _lib.MrfpHipError("a gated skip gradient reached its convolution without its gate: the skip alias was "
+                                        "also consumed by an operator outside mrfp_amd.ops (set MRFP_GATED_SKIP=0)")
+            cell[1] = False
         if dy is None:            # only the skip alias was used downstream
             return ungate(dskip), None, None, None, None, None, None, None, None
         stride, pad_h, pad_w, dil, Nphys, Ho, Wo = ctx.cfg
@@ -262,6 +409,7 @@ class _Conv2d(torch.autograd.Function):
                 dskip = _chk(dskip, "dskip")
                 if dskip.dtype != x.dtype:
                     dskip = dskip.to(x.dtype)
+            _lib.NOTE[0] = (N, C)
             if gate is not None:
                 call("mrfp_conv_fwd_gated", ptr(dy), ptr(pk.wd), None, ptr(dx), dt(dy), B, Ho, Wo, Nphys, Cphys, Cphys, R, S, H, W,
                      1, dil * (R - 1) - pad_h, dil * (S - 1) - pad_w, dil, stride, ptr(dskip), ptr(gate), stream())
@@ -273,7 +421,10 @@ class _Conv2d(torch.autograd.Function):
             M, Q = B * Ho * Wo, R * S * Cphys
             sink = grad_sink(weight)      # the parameter's slot in the flat gradient arena, when the harness owns it
             side = wgrad_stream(x.device) if sink is not None else None
-            if side is not None:
+            if sink is not None and GROUP_WGRAD[0] and L_single(B, H, W, Cphys, Ho, Wo, Nphys, x.element_size()):
+                _queue_wgrad((x.dtype, B, H, W, Cphys, C, N, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil), x, dy, sink, weight)
+                dw = None
+            elif side is not None:
                 # The weight gradient feeds nothing but the optimizer: it runs on a second HIP stream, concurrently with
                 # the dgrad chain of the main stream (its workgroups fill the tails / small-kernel gaps of that chain).
                 # Ordering: side waits for dy (an event on the main stream); the consumers of the arena (optimizer step,
@@ -420,11 +571,16 @@ def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] =
         raise _lib.MrfpHipError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], C))
     Nphys = phys_out if phys_out is not None else _round_up(N, epc)
     _LAST_STATS[0] = None
+    if _JOIN_QUEUED[0]:
+        _drop_stale_backward_state()
     out = _Conv2d.apply(x, weight, bias, st, ph, pw, dl, Nphys, want_skip)
     y, skip = out if want_skip else (out, None)
     if skip is not None:
         skip._mrfp_skip_alias = True      # its gradient goes to this convolution's dgrad epilogue and nowhere else
-        skip._mrfp_uses = [0]             # operators that consumed the alias so far (ops._chk): a gated gradient needs exactly one
+        # [operators that consumed the alias so far (ops._chk): a gated gradient needs exactly one, a gated gradient was issued]
+        skip._mrfp_uses = [0, False]
+        if y.grad_fn is not None:
+            y.grad_fn._mrfp_cell = skip._mrfp_uses     # (the autograd node IS the ctx of _Conv2d.backward)
     if _LAST_STATS[0] is not None and (phys_out is not None or Nphys == N):
         y._mrfp_colstats = _LAST_STATS[0]        # consumed by ops.batch_norm_act (statistics pass skipped)
     _LAST_STATS[0] = None

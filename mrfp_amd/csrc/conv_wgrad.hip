@@ -40,8 +40,24 @@ struct WgP {
     int M, Q;         // pixels, R*S*C
     int klen;         // pixels per split (multiple of the K' tile)
     int tiles;        // output tiles per split
+    int splits;       // K' splits per problem
+    int ngroup;       // problems in this launch (1: x / dy / slab above; > 1: WgGroup below, slabs back to back)
     unsigned xbytes, dybytes;
     FastDiv div_hw, div_w;   // by Ho*Wo and by Wo
+};
+
+// GROUPED launch: up to kWgMaxGroup weight-gradient problems of ONE geometry (the repeated blocks of a ResNet stage:
+// reference network/Resnet.py:579-585 _make_layer) in one grid.  The operand pointers travel in the kernel arguments (no
+// device-side table, no copy, graph-capturable); the work index is problem-major, so with the XCD-chunked order the tiles of
+// one problem share one L2.  22x the tiles of a layer-3 launch means 2-3 K' splits instead of 21-32: K' loops of ~190 tiles
+// per workgroup instead of 12 behind the same prologue, and 1/10 of the fp32 slab traffic.
+constexpr int kWgMaxGroup = 32;
+struct WgGroup {
+    const char* x[kWgMaxGroup];
+    const char* dy[kWgMaxGroup];
+};
+struct WgOut {
+    float* dw[kWgMaxGroup];
 };
 
 template <typename T> struct WgFrag;
@@ -109,7 +125,7 @@ template <> struct WgTile<float> { static constexpr int BKP = 32; };
 // the general kernel, on layers (M = 36 864 bottleneck 1x1) that are bound by exactly that instruction stream
 // (profiles/r02_experiments.md section 4: 31 us with or without any global traffic, MFMA time 11 us).
 template <typename T, int WM, int WN, bool DMA, bool DENSE = false>
-__global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {   // 2nd = waves per SIMD
+__global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, WgGroup grp) {   // 2nd = waves per SIMD
     static_assert(WM * WN == 4, "4 waves");
     static_assert(!DMA || sizeof(T) == 2, "LDS-DMA layout is for the 16-bit types");
     constexpr int BKP = WgTile<T>::BKP;
@@ -129,13 +145,23 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
     const int ntq = (p.Q + 64 * WN - 1) / (64 * WN);
     // 1-D grid over (split, tile), split-major, dealt to the XCDs in contiguous chunks: the tiles of one split read the
     // same pixel range of x and dy, so they share one L2 instead of pulling those rows into all eight
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    int work = xcd_remap(blockIdx.x, gridDim.x);
+    const char* xbase = p.x;
+    const char* dybase = p.dy;
+    int prob = 0;
+    if (p.ngroup > 1) {              // (uniform) problem-major work order
+        const int per = p.tiles * p.splits;
+        prob = work / per;
+        work -= prob * per;
+        xbase = grp.x[prob];
+        dybase = grp.dy[prob];
+    }
     const int split = work / p.tiles, tile = work - split * p.tiles;
     const int n0 = (tile / ntq) * 64 * WM, q0 = (tile % ntq) * 64 * WN;
     const int kbeg = split * p.klen;
     const int kend = min(p.M, kbeg + p.klen);
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dybase, 0, (int)p.dybytes, 0x00020000);
 
     // dY slots: dense rows; column fixed per thread
     const int yrow = t / CY;
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
     }
     }
 
-    float* out = p.slab + (size_t)split * p.N * p.Q;
+    float* out = p.slab + ((size_t)prob * p.splits + split) * p.N * p.Q;
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -326,10 +352,14 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p) {
 // was considered and not built -- the arriver of a tile would pull splits x 64 KB through ONE compute unit behind a ~3.5 us
 // device-scope fence, MI355X_MICROARCH.md -- DESIGN.md section 4.)  The OIHW stores are 4-byte scattered but few.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int N, int Q, int C, int Ctrue, int RS,
-                                                            float* __restrict__ dw, int accumulate) {
+                                                            float* __restrict__ dw, int accumulate, WgOut outs) {
     __shared__ float4 part[4][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t total4 = (int64_t)N * Q / 4, NQ = (int64_t)N * Q;
+    if (gridDim.y > 1) {             // grouped launch: problem blockIdx.y, its slabs back to back
+        slab += (size_t)blockIdx.y * splits * NQ;
+        dw = outs.dw[blockIdx.y];
+    }
     const int64_t i = (int64_t)blockIdx.x * 64 + o;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < total4) {
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 template <typename T, int WM, int WN, bool DMA, bool DENSE = false>
-static int launch_wgrad_v(const WgP& p, int splits, hipStream_t st) {
+static int launch_wgrad_v(const WgP& p, int splits, hipStream_t st, const WgGroup* grp) {
     constexpr int PY = 64 * WM * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);
     const int lds = WgTile<T>::BKP * (PY + PX);
     static bool attr_set = false;
@@ -384,30 +414,32 @@ static int launch_wgrad_v(const WgP& p, int splits, hipStream_t st) {
     }
     WgP q = p;
     q.tiles = ((p.N + 64 * WM - 1) / (64 * WM)) * ((p.Q + 64 * WN - 1) / (64 * WN));
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, DMA, DENSE>), dim3((unsigned)(q.tiles * splits)), dim3(256), lds, st, q);
+    q.splits = splits;
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, DMA, DENSE>), dim3((unsigned)(q.tiles * splits * q.ngroup)), dim3(256), lds, st, q, *grp);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
 
 // MRFP_WGRAD_DMA=0 keeps register staging for the 16-bit types (A/B measurements); fp32 always stages in registers
 template <typename T, int WM, int WN>
-static int launch_wgrad(const WgP& p, int splits, hipStream_t st) {
+static int launch_wgrad(const WgP& p, int splits, hipStream_t st, const WgGroup* grp) {
     static int dma = -1;
     if (dma < 0) { const char* e = getenv("MRFP_WGRAD_DMA"); dma = e ? atoi(e) : 1; }
     if (sizeof(T) == 2 && dma) {
         static int dense = -1;
         if (dense < 0) { const char* e = getenv("MRFP_WGRAD_DENSE"); dense = e ? atoi(e) : 1; }
         const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && p.H == p.Ho && p.W == p.Wo;
-        if (dense && pointwise) return launch_wgrad_v<T, WM, WN, sizeof(T) == 2, true>(p, splits, st);
-        return launch_wgrad_v<T, WM, WN, sizeof(T) == 2>(p, splits, st);
+        if (dense && pointwise) return launch_wgrad_v<T, WM, WN, sizeof(T) == 2, true>(p, splits, st, grp);
+        return launch_wgrad_v<T, WM, WN, sizeof(T) == 2>(p, splits, st, grp);
     }
-    return launch_wgrad_v<T, WM, WN, false>(p, splits, st);
+    return launch_wgrad_v<T, WM, WN, false>(p, splits, st, grp);
 }
 
-static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen, int64_t cap = 0) {
+static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen, int64_t cap = 0, int64_t group = 1) {
     wm = N <= 64 ? 1 : 2;
     const int wn = 4 / wm;
-    const int64_t tiles = ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
+    // (a grouped launch: `group` problems of this geometry fill the chip together; the split count is per problem)
+    const int64_t tiles = group * ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
     const int64_t nkt = (M + bkp - 1) / bkp;
     // Split count from a small cost model (times in us, constants fitted to the bench workload's per-launch timings):
     //   a CU that holds w = ceil(tiles*sp/256) workgroups needs w * (K' tiles per split) tile-steps of ~0.84 us, divided
@@ -429,7 +461,7 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& s
         for (int64_t c = 1; c <= smax; ++c) {
             const int64_t w = (tiles * c + 255) / 256, iters = (nkt + c - 1) / c;
             const double eff = w >= 3 ? 1.0 : w == 2 ? 0.85 : 0.6;
-            const double cost = (double)w * (double)iters * 0.84 / eff + (double)c * ((double)N * (double)Q * 8.0 / 3.0e6);
+            const double cost = (double)w * (double)iters * 0.84 / eff + (double)c * (double)group * ((double)N * (double)Q * 8.0 / 3.0e6);
             if (cost < best * 0.999) { best = cost; sp = c; }
         }
     }
@@ -455,28 +487,38 @@ int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q) {
     return (int64_t)(s32 > s64 ? s32 : s64) * N * Q * 4;
 }
 
-int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype, int64_t B, int64_t H, int64_t W,
-                    int64_t C, int64_t Ctrue, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
-                    int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, void* stream) {
-    MRFP_CHECK(x && dy && dw && ws && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
-               "conv_wgrad: bad arguments");
+static int wgrad_run(const void* const* xs, const void* const* dys, float* const* dws, int64_t count, void* ws, int dtype, int64_t B,
+                     int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho,
+                     int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, void* stream) {
+    MRFP_CHECK(xs && dys && dws && ws && count > 0 && count <= kWgMaxGroup && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 &&
+               Ho > 0 && Wo > 0, "conv_wgrad: bad arguments");
     MRFP_CHECK(dtype == MRFP_F32 || dtype == MRFP_BF16 || dtype == MRFP_F16, "conv_wgrad: unknown dtype %d", dtype);
     const int esz = dtype == MRFP_F32 ? 4 : 2;
     MRFP_CHECK((C * esz) % 16 == 0 && (ldn * esz) % 16 == 0 && ldn >= N && Ctrue <= C,
                "conv_wgrad: channel counts must make 16-byte chunks (C=%lld ldn=%lld)", (long long)C, (long long)ldn);
-    MRFP_CHECK(aligned16(x) && aligned16(dy), "conv_wgrad: x / dy must be 16-byte aligned");
+    for (int64_t g = 0; g < count; ++g)
+        MRFP_CHECK(xs[g] && dys[g] && dws[g] && aligned16(xs[g]) && aligned16(dys[g]), "conv_wgrad: x / dy must be 16-byte aligned, dw non-null");
     MRFP_CHECK(B * Ho * Wo < (1LL << 31), "conv_wgrad: tensor too large");
     WgP p;
-    p.x = (const char*)x; p.dy = (const char*)dy; p.slab = (float*)ws;
+    p.x = (const char*)xs[0]; p.dy = (const char*)dys[0]; p.slab = (float*)ws;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldn = (int)ldn;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil;
     p.Q = (int)(R * S * C);
+    p.ngroup = (int)count;
+    WgGroup grp;
+    WgOut outs;
+    for (int g = 0; g < kWgMaxGroup; ++g) {
+        grp.x[g] = (const char*)xs[g < count ? g : 0];
+        grp.dy[g] = (const char*)dys[g < count ? g : 0];
+        outs.dw[g] = dws[g < count ? g : 0];
+    }
     // Both operands are read through 32-bit buffer-descriptor offsets: an activation above kOOB bytes is walked in batch
     // ranges, every range one wgrad + reduction pair on the stream, the later ones adding to dw (fixed order: reproducible)
     const int64_t ximg = H * W * C * esz, yimg = Ho * Wo * ldn * esz;
     MRFP_CHECK(ximg < (int64_t)kOOB && yimg < (int64_t)kOOB, "conv_wgrad: one image exceeds the 3.75 GB buffer-descriptor range");
     int64_t bmax = (int64_t)(kOOB - 1) / (ximg > yimg ? ximg : yimg);
+    MRFP_CHECK(count == 1 || bmax >= B, "conv_wgrad_grouped: the activations of a grouped launch must fit one 3.75 GB buffer range each");
     int dbg_drop = 0;
     {   // timing-only diagnostics (see mrfp_conv_fwd)
         static int dbg = -1;
@@ -486,29 +528,50 @@ int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtyp
     p.div_hw = make_fastdiv((unsigned)(Ho * Wo)); p.div_w = make_fastdiv((unsigned)Wo);
     hipStream_t st = (hipStream_t)stream;
     int wm0, cap, klen0;
-    wgrad_plan(B * Ho * Wo, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm0, cap, klen0);     // what `ws` was sized for
+    wgrad_plan(B * Ho * Wo, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm0, cap, klen0, 0, count);     // what `ws` was sized for
     for (int64_t b0 = 0; b0 < B; b0 += bmax) {
         const int64_t bc = B - b0 < bmax ? B - b0 : bmax;
         p.B = (int)bc;
         p.M = (int)(bc * Ho * Wo);
-        p.x = (const char*)x + b0 * ximg;
-        p.dy = (const char*)dy + b0 * yimg;
+        p.x = (const char*)xs[0] + b0 * ximg;
+        p.dy = (const char*)dys[0] + b0 * yimg;
         p.xbytes = (dbg_drop & 1) ? 0u : (unsigned)(bc * ximg);
         p.dybytes = (dbg_drop & 2) ? 0u : (unsigned)(bc * yimg);
         int wm, splits;
-        wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen, cap);
+        wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen, cap, count);
         int rc;
-        if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st) : launch_wgrad<float, 2, 2>(p, splits, st);
-        else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st) : launch_wgrad<f16, 2, 2>(p, splits, st);
-        else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st) : launch_wgrad<bf16, 2, 2>(p, splits, st);
+        if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st, &grp) : launch_wgrad<float, 2, 2>(p, splits, st, &grp);
+        else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st, &grp) : launch_wgrad<f16, 2, 2>(p, splits, st, &grp);
+        else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st, &grp) : launch_wgrad<bf16, 2, 2>(p, splits, st, &grp);
         if (rc) return rc;
         const int64_t total4 = N * (int64_t)p.Q / 4;          // Q = R*S*C and C*esz % 16 == 0  =>  Q % 4 == 0
         const int64_t blocks = (total4 + 63) / 64;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, splits, (int)N,
-                           p.Q, (int)C, (int)Ctrue, (int)(R * S), dw, b0 > 0 ? 1 : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, (const float*)ws, splits, (int)N,
+                           p.Q, (int)C, (int)Ctrue, (int)(R * S), dws[0], b0 > 0 ? 1 : 0, outs);
         MRFP_LAUNCH_CHECK();
     }
     return 0;
+}
+
+int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype, int64_t B, int64_t H, int64_t W,
+                    int64_t C, int64_t Ctrue, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
+                    int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, void* stream) {
+    return wgrad_run(&x, &dy, &dw, 1, ws, dtype, B, H, W, C, Ctrue, N, ldn, R, S, Ho, Wo, stride, pad_h, pad_w, dil, stream);
+}
+
+int64_t mrfp_conv_wgrad_group_max(void) { return kWgMaxGroup; }
+
+int64_t mrfp_conv_wgrad_grouped_ws_bytes(int64_t M, int64_t N, int64_t Q, int64_t count) {
+    int wm, s32, s64, klen;
+    mrfp::wgrad_plan(M, N, Q, 32, wm, s32, klen, 0, count);
+    mrfp::wgrad_plan(M, N, Q, 64, wm, s64, klen, 0, count);
+    return (int64_t)(s32 > s64 ? s32 : s64) * count * N * Q * 4;
+}
+
+int mrfp_conv_wgrad_grouped(const void* const* xs, const void* const* dys, float* const* dws, int64_t count, void* ws, int dtype,
+                            int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn, int64_t R, int64_t S,
+                            int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, void* stream) {
+    return wgrad_run(xs, dys, dws, count, ws, dtype, B, H, W, C, Ctrue, N, ldn, R, S, Ho, Wo, stride, pad_h, pad_w, dil, stream);
 }
 
 }  // extern "C"

@@ -21,6 +21,7 @@ from torch import nn
 
 from . import ops
 from .config import cfg
+from .conv import wgrad_boundary
 from .network import Resnet
 from .network.mynn import (HipBatchNorm2d, HipConv2d, Norm2d, Upsample, initialize_weights,
                            initialize_weights_kaimingnormal_forOC)
@@ -45,7 +46,8 @@ class ReferenceRandom:
             initialize_weights_kaimingnormal_forOC(conv)
             initialize_weights_kaimingnormal_forOC(bn)
         from . import conv as conv_mod
-        conv_mod.repack_weights([c.weight for c, _ in model.hrfp_layers()], tag="hrfp")   # one pack launch instead of one per layer
+        conv_mod.repack_weights([c.weight for c, _ in model.hrfp_layers()], tag="hrfp",
+                                biases=[c.bias for c, _ in model.hrfp_layers()])            # one pack launch instead of one per layer
 
     def np_noise(self, which, B, C, device):
         # torch.normal(mean_tensor, std_tensor) as the reference calls it (deepv3.py:274-275) is, inside ATen,
@@ -207,22 +209,26 @@ class _DeepLabBase(nn.Module):
 
     def _low(self, t, w_arr):
         """stem output -> low-level features (256 ch, 1/4): layer1 (reference deepv3.py:331-333) / mod3."""
+        # (conv.wgrad_boundary: when backward reaches this activation, the stage behind it has queued all its weight gradients and
+        #  they are issued as grouped launches -- mrfp_amd/conv.py)
         if hasattr(self, "layer1"):
-            return self.layer1([t, w_arr])[0]
-        return self.mod3(t)
+            return self.layer1([wgrad_boundary(t), w_arr])[0]
+        return self.mod3(wgrad_boundary(t))
 
     def _high(self, t, w_arr, fourier=None):
         """low-level features -> ASPP input: layer2..layer4 (reference deepv3.py:338-344) / mod4..mod7 + bn_out."""
         if hasattr(self, "layer1"):
-            t = self.layer2([t, w_arr])
+            t = self.layer2([wgrad_boundary(t), w_arr])
             if fourier is not None:
                 t[0] = fourier.at("layer2", t[0])
             self._tap("layer2", t[0])
+            t[0] = wgrad_boundary(t[0])
             t = self.layer3(t)
             self._tap("layer3", t[0])
-            return self.layer4(t)[0]
-        t = self.mod7(self.mod6(self.mod5(self.mod4(t))))
-        return self.bn_out[0].fused(t, relu=True)
+            t[0] = wgrad_boundary(t[0])
+            return wgrad_boundary(self.layer4(t)[0])
+        t = self.mod7(self.mod6(self.mod5(wgrad_boundary(self.mod4(wgrad_boundary(t))))))
+        return wgrad_boundary(self.bn_out[0].fused(t, relu=True))
 
     def _final1(self, d):
         d = self.final1[1].fused(self.final1[0](d), relu=True)

@@ -171,15 +171,28 @@ class GradSync:
         self.on_gpu = opt.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None
         self._index = {id(p): i for i, p in enumerate(opt.params)}
-        for i, p in enumerate(opt.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
         from . import ops
+        for i, p in enumerate(opt.params):
+            p.register_post_accumulate_grad_hook(self._make_autograd_hook(i, ops.GRAD_DEFERRED))
         ops.GRAD_NOTIFY[0] = self._notify     # gradients written straight into the arena by the HIP backward kernels
 
     def _notify(self, param):
         i = self._index.get(id(param))
         if i is not None:
             self._make_hook(i)(param)
+
+    def _make_autograd_hook(self, i, deferred):
+        """autograd's post-accumulate hook: fires when the parameter's backward node has RUN -- also when that node returned None
+        because its kernel writes the arena directly, and also when it only QUEUED the weight-gradient launch (conv._queue_wgrad:
+        grouped, deferred weight gradients).  A queued gradient has not been written: it is reported by ops.notify_grad when its
+        launch has been issued, and ignored here."""
+        inner = self._make_hook(i)
+
+        def hook(param):
+            if id(param) in deferred:
+                return
+            inner(param)
+        return hook
 
     def _make_hook(self, i):
         def hook(_param):
@@ -225,6 +238,7 @@ class GradSync:
     def finish(self):
         """Blocks the compute stream until every bucket has been reduced; returns the 1/world scale."""
         from . import conv
+        conv.flush_wgrads()                          # (queued grouped weight gradients: backward's end callback has issued them already)
         conv.join_wgrad_stream()                     # weight gradients are computed on a second stream (mrfp_amd/conv.py)
         if not self.enabled:
             return 1.0
@@ -352,7 +366,11 @@ class Trainer:
             static_img, static_lab = img.clone(), label.clone()
             self.model.rng = _Fixed(rng, tog)
             try:
-                side = torch.cuda.Stream()
+                # ONE capture stream for every key: autograd's gradient accumulators remember the stream they first ran on, and a
+                # capture on another stream is forked / joined once per parameter (a cross-queue barrier each at replay)
+                if getattr(self, "_graph_stream", None) is None:
+                    self._graph_stream = torch.cuda.Stream()
+                side = self._graph_stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):           # eager warm-up on a side stream (lazy tables, attributes, packs)
                     loss = self._fwd_bwd(static_img, static_lab).detach()
@@ -365,7 +383,8 @@ class Trainer:
                 # the replay of such a graph pays a cross-queue barrier per fork (35 vs 15 ms on ResNet-50 8x512^2)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    static_loss = self._fwd_bwd(static_img, static_lab)
+                    static_loss = self._fwd_bwd(static_img, static_lab).detach()    # only the value is read at replay: no autograd graph
+                                                                                      # (and its accumulator nodes) kept alive per key
             finally:
                 self.model.rng = rng
             for m in self._bns:                           # the capture pass ran the Python side of every layer once more

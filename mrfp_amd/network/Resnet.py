@@ -161,10 +161,11 @@ class _Trunk(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def _stages(self, x, w_arr):
-        x_tuple = self.layer1([x, w_arr])
-        x_tuple = self.layer2(x_tuple)
-        x_tuple = self.layer3(x_tuple)
-        x_tuple = self.layer4(x_tuple)
+        from ..conv import wgrad_boundary      # stage boundaries: the queued weight gradients of a stage are issued as grouped launches
+        x_tuple = self.layer1([wgrad_boundary(x), w_arr])
+        for layer in (self.layer2, self.layer3, self.layer4):
+            x_tuple[0] = wgrad_boundary(x_tuple[0])
+            x_tuple = layer(x_tuple)
         return x_tuple[0]
 
 

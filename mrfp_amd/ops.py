@@ -25,6 +25,8 @@ CL = torch.channels_last
 # (harness.FlatArena sets `_mrfp_direct`), backward kernels write the parameter gradient straight into that view
 # (no temporary, no autograd accumulate kernel) and report it through GRAD_NOTIFY (data-parallel bucket counting).
 GRAD_NOTIFY = [None]
+GRAD_DEFERRED = set()      # id(param) of weights whose gradient launch is queued (conv._queue_wgrad): not written yet -- autograd's
+                           # post-accumulate hook fires for them all the same and must not count them as arrived (harness.GradSync)
 
 
 def grad_sink(param):
@@ -184,21 +186,34 @@ GATED_SKIP = [os.environ.get("MRFP_GATED_SKIP", "1") != "0"]   # ... and the ski
 SYNC_BN_CALLS = [0]       # BatchNorm layers that exchanged their statistics across ranks (tests)
 
 
+_SYNC_BN_GROUP = [None]     # the statistics' own communicator (created once, collectively, at the first synchronised layer)
+_SYNC_BN_COUNTS = {}        # (local element count, world) -> element count over all ranks
+
+
 def _sync_bn_group():
     """The process group BatchNorm statistics are summed over, or None: cfg.MODEL.SYNC_BN (the reference's syncbn switch,
     config.py:92-93: torch.nn.SyncBatchNorm) with more than one rank.  Off by default: 16 images per GPU is the reference's
-    own statistical population; it matters for per-GPU batches below that (configs[4]: 2 images)."""
+    own statistical population; it matters for per-GPU batches below that (configs[4]: 2 images).
+    The statistics travel on their OWN communicator, never on the one harness.GradSync issues its hook-driven bucket all-reduces
+    on: a bucket whose gradients arrive in a rank-dependent order (a tensor without gradient on one rank) is launched at a
+    rank-dependent point between two BatchNorm collectives, and on one communicator that would mis-pair them."""
     import torch.distributed as dist
     from .config import cfg
-    if not cfg.MODEL.SYNC_BN or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() < 2:
+    if not cfg.MODEL.SYNC_BN or not dist.is_available() or not dist.is_initialized():
         return None
-    return dist.group.WORLD
+    if dist.get_world_size() < 2 and os.environ.get("MRFP_FORCE_SYNC") != "1":     # (forced: the one-rank rehearsal over RCCL)
+        return None
+    if _SYNC_BN_GROUP[0] is None:
+        _SYNC_BN_GROUP[0] = dist.new_group()        # collective: every rank reaches its first synchronised layer in the same forward
+    return _SYNC_BN_GROUP[0]
 
 
 def _allreduce_stats(ws, rows, C, count, group):
     """Per-channel (sum, second sum) partial rows of THIS rank -> the same two sums over all ranks, as a 2-row workspace (fp32
     high part + remainder of the fp64 totals, which the finalize kernels add in fp64) and the global element count.  A few KB:
-    torch ops + one all-reduce of 2 C + 1 doubles (torch.nn.SyncBatchNorm exchanges the same quantities)."""
+    torch ops + one all-reduce of 2 C + 1 doubles (torch.nn.SyncBatchNorm exchanges the same quantities).  The global count is
+    read back from the device ONCE per local count (one host synchronisation per layer shape, in the first step) and cached:
+    per-rank batch sizes are fixed over a run (drop_last loaders, as the reference's, main.py:424-430)."""
     import torch.distributed as dist
     tot = torch.zeros(2 * C + 1, dtype=torch.float64, device=ws.device)
     tot[:2 * C] = ws.view(rows, 2 * C).sum(0, dtype=torch.float64)
@@ -207,7 +222,13 @@ def _allreduce_stats(ws, rows, C, count, group):
     hi = tot[:2 * C].float()
     lo = (tot[:2 * C] - hi.double()).float()
     SYNC_BN_CALLS[0] += 1
-    return torch.stack([hi, lo]).contiguous(), int(round(tot[2 * C].item()))
+    total = 0
+    if count:
+        key = (int(count), dist.get_world_size(group))
+        total = _SYNC_BN_COUNTS.get(key)
+        if total is None:
+            total = _SYNC_BN_COUNTS[key] = int(round(tot[2 * C].item()))
+    return torch.stack([hi, lo]).contiguous(), total
 
 
 class _BatchNormAct(torch.autograd.Function):
@@ -310,6 +331,9 @@ class _BatchNormAct(torch.autograd.Function):
             if ctx.gate_skip and ctx.needs_input_grad[5] and ctx.alias_uses is not None and ctx.alias_uses[0] == 1:
                 dres = dy.view_as(dy)                  # unmasked; the consumer applies the mask (conv._Conv2d.backward / conv.ungate)
                 dres._mrfp_gate = (y, dres._version)
+                # told to the convolution that owns the alias: if what reaches it is not this tagged tensor (a consumer of the alias
+                # that bypassed _chk made autograd sum it into a fresh one), it raises instead of using it as if it were masked
+                ctx.alias_uses[1] = True
                 call("mrfp_affine_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(dx), None, dt(dy), B, Ho, Wo, C, ptr(P), ptr(Q), ptr(R), 0,
                      stream())
             else:

@@ -25,7 +25,7 @@ DEV = "cuda:0"
 def _make(trunk, dtype, gain=1.0):
     from mrfp_amd import deepv3
     from mrfp_amd.config import cfg
-    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE, cfg.MODEL.FUSE_UPSAMPLE_CE = "hip", dtype, True
+    cfg.MODEL.ACT_DTYPE, cfg.MODEL.FUSE_UPSAMPLE_CE = dtype, True
     with contextlib.redirect_stdout(io.StringIO()):
         m = deepv3.MRFPPlus(19, trunk=trunk, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
     sd = synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=0, residual_gain=gain)

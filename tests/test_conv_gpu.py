@@ -26,10 +26,10 @@ CASES = [
     (2, 256, 12, 10, 48, 1, 1, 0, 1, False),     # bot_fine
     (2, 256, 12, 10, 19, 1, 1, 0, 1, True),      # final2 (N padded to a chunk)
     (3, 64, 33, 31, 64, 3, 1, 1, 1, False),      # M not a multiple of the tile
-    (2, 128, 240, 240, 256, 3, 1, 1, 1, True),   # enough rows and K tiles for the 256x256 (8-wave, LDS-DMA) tile
-    (2, 128, 240, 236, 256, 3, 1, 2, 2, False),  # 256x256 tile, dilated, ragged M
-    (2, 1152, 244, 240, 256, 1, 1, 0, 1, False), # 256x256 tile on a 1x1 conv with 18 K tiles
-    (2, 304, 240, 240, 256, 3, 1, 1, 1, False),  # big tile with taps straddling K tiles (304 channels)
+    (2, 128, 240, 240, 256, 3, 1, 1, 1, True),   # enough rows and K tiles for the 192x128 tile / row-reuse kernel
+    (2, 128, 240, 236, 256, 3, 1, 2, 2, False),  # 192x128 tile, dilated, ragged M
+    (2, 1152, 244, 240, 256, 1, 1, 0, 1, False), # long-K 1x1 conv with 18 K tiles
+    (2, 304, 240, 240, 256, 3, 1, 1, 1, False),  # taps straddling K tiles (304 channels)
     # the B-stationary kernel (16-bit types, pointwise, C in {64, 128, 256}, N >= 128): every K depth, ragged M (not a
     # multiple of the 64-row tile), N that ends inside a 128-column panel / inside a 16-column block, one-tile problems
     (2, 64, 20, 18, 256, 1, 1, 0, 1, False),
@@ -233,6 +233,79 @@ def test_repeated_launches_are_bit_identical(shape):
     for y, s in zip(ys[1:], sts[1:]):
         assert torch.equal(ys[0], y) and torch.equal(sts[0], s)
     assert ((ys[0].float() - ref).abs().max() / ref.abs().max()).item() < 1.5e-2
+
+
+def _wgrad_single(x, dy, N, C, k, stride, pad, dil):
+    from mrfp_amd import _lib
+    from mrfp_amd._lib import call, dt, ptr, stream
+    B, Cp, H, W = x.shape
+    _, Np, Ho, Wo = dy.shape
+    ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_ws_bytes(B * Ho * Wo, N, k * k * Cp)), dtype=torch.uint8, device=DEV)
+    dw = torch.full((N, C, k, k), float("nan"), device=DEV)
+    call("mrfp_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), dt(x), B, H, W, Cp, C, N, Np, k, k, Ho, Wo, stride, pad, pad, dil, stream())
+    return dw
+
+
+def _wgrad_grouped(xs, dys, N, C, k, stride, pad, dil):
+    import ctypes
+    from mrfp_amd import _lib
+    from mrfp_amd._lib import call, dt, ptr, stream
+    B, Cp, H, W = xs[0].shape
+    _, Np, Ho, Wo = dys[0].shape
+    n = len(xs)
+    ws = torch.empty(int(_lib.lib().mrfp_conv_wgrad_grouped_ws_bytes(B * Ho * Wo, N, k * k * Cp, n)), dtype=torch.uint8, device=DEV)
+    dws = [torch.full((N, C, k, k), float("nan"), device=DEV) for _ in range(n)]
+    arr = ctypes.c_void_p * n
+    call("mrfp_conv_wgrad_grouped", arr(*[ptr(t) for t in xs]), arr(*[ptr(t) for t in dys]), arr(*[ptr(t) for t in dws]), n, ptr(ws),
+         dt(xs[0]), B, H, W, Cp, C, N, Np, k, k, Ho, Wo, stride, pad, pad, dil, stream())
+    return dws
+
+
+# (B, Cin, H, W, Cout, k, stride, pad, dil, problems)
+GROUP_CASES = [
+    (4, 256, 48, 48, 1024, 1, 1, 0, 1, 22),      # layer3 conv3 (dense pointwise kernel)
+    (4, 1024, 48, 48, 256, 1, 1, 0, 1, 22),      # layer3 conv1
+    (4, 256, 48, 48, 256, 3, 1, 1, 1, 22),       # layer3 conv2 (gather kernel)
+    (2, 64, 40, 36, 64, 3, 1, 1, 1, 2),          # N <= 64: the 64x256 tile, ragged M
+    (3, 128, 33, 31, 128, 3, 2, 1, 1, 3),        # strided, M not a multiple of the K' tile
+    (2, 512, 24, 24, 512, 3, 1, 2, 2, 2),        # dilated (layer4)
+    (2, 304, 12, 10, 256, 3, 1, 1, 1, 5),        # channel-padded operand (Ctrue < C)
+    (2, 256, 12, 10, 19, 1, 1, 0, 1, 32),        # the group limit; N padded to a chunk in dy
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", GROUP_CASES)
+def test_grouped_wgrad_equals_the_single_launches(dtype, case):
+    """mrfp_conv_wgrad_grouped: `problems` weight gradients of one geometry in one launch (reference network/Resnet.py:579-585: the
+    repeated Bottlenecks of a stage).  Every problem's result against torch's convolution gradient of the same rounded operands
+    and against the single launch (same products, another association of the K' splits: fp32 rounding apart), and a second
+    grouped launch bit-identical to the first (fixed summation order)."""
+    from mrfp_amd import conv
+    B, C, H, W, N, k, stride, pad, dil, n = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    epc = 4 if dtype == torch.float32 else 8
+    Cp, Np = conv._round_up(C, 64 if C == 304 else epc), conv._round_up(N, epc)
+    Ho, Wo = conv._out_size(H, k, stride, pad, dil), conv._out_size(W, k, stride, pad, dil)
+    xs, dys = [], []
+    for _ in range(n):
+        x = torch.zeros(B, H, W, Cp, device=DEV, dtype=dtype)
+        x[..., :C].normal_(generator=g)
+        dy = torch.zeros(B, Ho, Wo, Np, device=DEV, dtype=dtype)
+        dy[..., :N].normal_(generator=g)
+        xs.append(x.permute(0, 3, 1, 2))
+        dys.append(dy.permute(0, 3, 1, 2))
+    a = _wgrad_grouped(xs, dys, N, C, k, stride, pad, dil)
+    b = _wgrad_grouped(xs, dys, N, C, k, stride, pad, dil)
+    tol = 1e-5 if dtype == torch.float32 else 2e-5          # (bf16 operands are exact inputs; the accumulation is fp32 in both)
+    for i in range(n):
+        assert torch.equal(a[i], b[i])
+        assert torch.isfinite(a[i]).all()
+        single = _wgrad_single(xs[i], dys[i], N, C, k, stride, pad, dil)
+        assert relerr(a[i], single) < tol
+        if i in (0, n - 1):
+            ref = torch.nn.grad.conv2d_weight(xs[i][:, :C].float().cpu(), (N, C, k, k), dys[i][:, :N].float().cpu(), stride, pad, dil)
+            assert relerr(a[i], ref) < (2e-5 if dtype == torch.float32 else 1e-4)
 
 
 def test_row_reuse_kernels_in_subprocess():

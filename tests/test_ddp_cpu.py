@@ -209,20 +209,30 @@ def test_poly_lr_and_sgd_rule_host_formula():
     assert poly_lr_factor(40000) == 0.0
 
 
-def test_bench_gpus_flag_builds_a_child_launch(monkeypatch):
+class _FakeChild:
+    def __init__(self, out, err, rc):
+        self.stdout, self.stderr, self._rc = iter(out), iter(err), rc
+
+    def wait(self):
+        return self._rc
+
+
+def test_bench_gpus_flag_builds_a_child_launch(monkeypatch, capsys):
     """`python bench.py --gpus N` (N > 1, no WORLD_SIZE) must start N ranks through torch.distributed.run as a CHILD
-    process on the loopback address and hand back its exit code (the GPU end-to-end form is tests/test_ddp_gpu.py)."""
+    process on the loopback address, relay its output and hand back its exit code (the GPU end-to-end form is
+    tests/test_ddp_gpu.py)."""
     import subprocess
     sys.path.insert(0, ROOT)
     import bench
     seen = {}
 
-    def fake_call(cmd, env=None, cwd=None):
+    def fake_popen(cmd, env=None, cwd=None, **kw):
         seen.update(cmd=cmd, env=env, cwd=cwd)
-        return 7
-    monkeypatch.setattr(subprocess, "call", fake_call)
+        return _FakeChild(['{"metric": "x"}\n'], ["some warning\n"], 7)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("MRFP_BENCH_PORT", raising=False)
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
@@ -230,3 +240,155 @@ def test_bench_gpus_flag_builds_a_child_launch(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert os.path.basename(cmd[-7]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert int(seen["env"]["OMP_NUM_THREADS"]) >= 1
+    assert '{"metric": "x"}' in capsys.readouterr().out                  # the child's JSON line is relayed
+
+
+def test_bench_launcher_retries_once_when_the_probed_port_was_taken(monkeypatch):
+    """The rendezvous port is probed by bind-and-release; if another process takes it before torch.distributed.run binds it the
+    child dies with EADDRINUSE: ONE more attempt in a FRESH child on a fresh port (never a re-exec), none after a result line or
+    any other failure."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    launches = []
+    script = [(["\n"], ["RuntimeError: The server socket has failed to listen on any local network address. "
+                        "port: 1, useIpv6: 0, code: -98, name: EADDRINUSE, message: address already in use\n"], 1),
+              (['{"metric": "x"}\n'], [], 0)]
+
+    def fake_popen(cmd, env=None, cwd=None, **kw):
+        launches.append(cmd[cmd.index("--master-port") + 1])
+        out, err, rc = script[len(launches) - 1]
+        return _FakeChild(out, err, rc)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.delenv("MRFP_BENCH_PORT", raising=False)
+    ports = iter(["41001", "41002", "41003"])
+    monkeypatch.setattr(bench, "_free_port", lambda: next(ports))
+
+    class A:
+        gpus = 8
+    assert bench.launch_ranks(A(), argv=["--gpus", "8"]) == 0
+    assert launches == ["41001", "41002"]
+    # any other failure: no second attempt
+    del launches[:]
+    script[0] = (["\n"], ["Traceback ...\n"], 3)
+    assert bench.launch_ranks(A(), argv=["--gpus", "8"]) == 3 and launches == ["41003"]
+
+
+_STUB = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+from mrfp_amd.harness import FlatArena, GradSync
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.ReLU(), torch.nn.Linear(33, 5))
+arena = FlatArena(net)
+sync = GradSync(arena, bucket_mb=64 * 4 / (1 << 20))
+arena.zero_grad(); sync.begin()
+torch.manual_seed(100 + dist.get_rank())
+net(torch.randn(4, 7)).sum().backward()
+scale = sync.finish()
+ones = torch.ones(1); dist.all_reduce(ones)
+g = arena.flat_g * scale
+ref = [torch.zeros_like(g) for _ in range(dist.get_world_size())]
+dist.all_gather(ref, g)
+ok = all(torch.equal(ref[0], r) for r in ref)
+dist.barrier()
+if dist.get_rank() == 0:
+    print('{"ranks_seen": %%d, "equal": %%s, "omp": "%%s"}' %% (int(ones.item()), "true" if ok else "false", os.environ.get("OMP_NUM_THREADS")))
+dist.destroy_process_group()
+'''
+
+
+def test_eight_rank_launch_rehearsal_on_cpu(tmp_path, capfd):
+    """The driver's 8-GPU run is the first time eight ranks meet (this pool gives the builder one GPU and at most six processes
+    on it): rehearse what does not need the card -- bench.launch_ranks itself starting EIGHT ranks through torch.distributed.run
+    on the loopback address, the rendezvous, the bucketed gradient exchange over the data-path group (gloo, CPU arenas) and the
+    `ranks_seen` all-reduce -- with a stub rank program."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB % ROOT)
+
+    class A:
+        gpus = 8
+    env_before = os.environ.get("MRFP_BENCH_PORT")
+    assert env_before is None
+    rc = bench.launch_ranks(A(), script=str(stub), argv=[])
+    assert rc == 0
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["ranks_seen"] == 8 and out["equal"] is True and int(out["omp"]) >= 1
+
+
+def _worker_deferred(outdir):
+    """One rank, MRFP_FORCE_SYNC=1 (the bucket machinery runs at world size 1): a backward node that only QUEUES its weight
+    gradient (what conv._queue_wgrad does for the grouped launches) must hold its bucket back until ops.notify_grad reports
+    the launch -- autograd's post-accumulate hook fires for the parameter as soon as the node has run."""
+    sys.path.insert(0, ROOT)
+    os.environ["MRFP_FORCE_SYNC"] = "1"
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "store"), rank=0, world_size=1)
+    from mrfp_amd import ops
+    from mrfp_amd.harness import FlatArena, GradSync
+    queue = []
+
+    class Deferred(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            ctx.w = w
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            ops.GRAD_DEFERRED.add(id(ctx.w))
+            queue.append((ctx.w, dy.t() @ x))
+            return dy @ w, None
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(7, 33)
+            self.w = torch.nn.Parameter(torch.randn(40, 33))
+            self.c = torch.nn.Linear(40, 3)
+
+        def forward(self, x):
+            return self.c(Deferred.apply(torch.relu(self.a(x)), self.w)).sum()
+
+    torch.manual_seed(0)
+    net = Net()
+    arena = FlatArena(net)
+    sync = GradSync(arena, bucket_mb=100 * 4 / (1 << 20))       # buckets (from the end): {c.*}, {w}, {a.*}
+    launched = []
+    real = sync._launch
+    sync._launch = lambda b: (launched.append(b), real(b))[1]
+    w_index = [i for i, p in enumerate(arena.params) if p is net.w][0]
+    wb = sync.bucket_of[w_index]
+    arena.zero_grad()
+    sync.begin()
+    net(torch.randn(5, 7)).backward()
+    held = wb not in launched and all(b < wb for b in launched)        # w's bucket and every later one wait for the queued launch
+    for w, g in queue:                                                  # the "flush": write the gradient, then report it
+        w.grad.copy_(g)
+        ops.GRAD_DEFERRED.discard(id(w))
+        ops.notify_grad(w)
+    after = list(launched)
+    sync.finish()
+    torch.save({"held": held, "after": after, "n": len(sync.buckets), "wb": wb, "gw": net.w.grad.clone(), "ref": queue[0][1]},
+               os.path.join(outdir, "d.pt"))
+    dist.destroy_process_group()
+
+
+def test_deferred_weight_gradient_holds_its_bucket_back(tmp_path):
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_worker_deferred, args=(str(tmp_path),))
+    p.start()
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    out = torch.load(os.path.join(str(tmp_path), "d.pt"))
+    assert out["n"] >= 3 and out["held"]
+    assert out["after"] == list(range(out["n"]))                         # the notification released every bucket, in index order
+    torch.testing.assert_close(out["gw"], out["ref"])

@@ -18,7 +18,7 @@ def _build(seed=0):
     sys.path.insert(0, ROOT)
     from mrfp_amd.config import cfg
     from mrfp_amd.network import Resnet
-    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.float32
+    cfg.MODEL.ACT_DTYPE = torch.float32
     torch.manual_seed(seed)
     net = Resnet.resnet18(pretrained=False, wt_layer=[0, 0, 4, 4, 0, 0, 0])
     del net.fc, net.avgpool
@@ -229,6 +229,30 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     assert out["value"] > 0 and out["cpu_baseline"] is None
 
 
+def test_six_rank_rehearsal_on_the_one_gpu():
+    """The widest rehearsal this pool allows on the card (at most six processes of one user may hold the GPU; the eight-rank
+    launch itself is rehearsed on the CPU, tests/test_ddp_cpu.py::test_eight_rank_launch_rehearsal_on_cpu): `python bench.py
+    --gpus 6` in the driver's form -- bench.py starts the ranks itself -- with every rank on cuda:0 over gloo.  Shows what two
+    ranks cannot: the rendezvous of more than two processes, port handling, OMP_NUM_THREADS under oversubscription, six HIP
+    contexts with eight hardware queues each on one device."""
+    import json
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MRFP_BENCH_SHARE_GPU="1", MRFP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1",
+           "--trunk", "resnet-50", "--size", "64", "--batch", "2", "--dtype", "bf16"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 6 and out["ranks_seen"] == 6 and out["config"]["global_batch"] == 12
+    assert out["value"] > 0 and wall < 300, wall
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # cfg.MODEL.SYNC_BN (reference config.py:105-107: torch.nn.SyncBatchNorm when args.syncbn): BatchNorm statistics over the
 # batches of all ranks.  Two ranks with two images each against ONE process with the four images: forward output, running
@@ -308,3 +332,40 @@ def test_sync_batchnorm_two_ranks_equal_one_process_on_the_whole_batch(tmp_path)
     sys.path.insert(0, ROOT)
     local = _syncbn_run(slice(0, 2), False)
     assert rel(local["plain"]["y"], full["plain"]["y"][0:2]) > 1e-3
+
+
+def _worker_syncbn_rccl(outdir):
+    """cfg.MODEL.SYNC_BN over RCCL itself (backend "nccl", world size 1 forced with MRFP_FORCE_SYNC=1 -- RCCL refuses two ranks on
+    one device): the statistics' own communicator (dist.new_group), its float64 all-reduce on the device, the cached global
+    count (no host synchronisation after the first call of a shape)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29767", HSA_ENABLE_IPC_MODE_LEGACY="0", MRFP_FORCE_SYNC="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sys.path.insert(0, ROOT)
+    from mrfp_amd import ops
+    before = ops.SYNC_BN_CALLS[0]
+    out = _syncbn_run(slice(0, 4), True)
+    again = _syncbn_run(slice(0, 4), True)
+    assert ops.SYNC_BN_CALLS[0] - before == 12 and ops._SYNC_BN_GROUP[0] is not None and ops._SYNC_BN_GROUP[0] is not dist.group.WORLD
+    assert list(ops._SYNC_BN_COUNTS.values()) == [4 * 10 * 12]          # one cached count: read back once
+    for name in out:
+        for k in out[name]:
+            assert torch.equal(out[name][k], again[name][k]), (name, k)
+    torch.save(out, os.path.join(outdir, "sbn_rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_over_rccl_at_world_size_one(tmp_path):
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_worker_syncbn_rccl, args=(str(tmp_path),))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    full = _syncbn_run(slice(0, 4), False)
+    got = torch.load(os.path.join(str(tmp_path), "sbn_rccl.pt"))
+    for name in ("plain", "res", "conv"):
+        for k in ("y", "dx", "dw", "db", "rm", "rv"):
+            a, b = got[name][k], full[name][k]
+            assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 5e-5, (name, k)

@@ -98,7 +98,6 @@ def test_upsample_ce_f16():
 def _model(dtype):
     from mrfp_amd import deepv3
     from mrfp_amd.config import cfg
-    cfg.MODEL.CONV_BACKEND = "hip"
     cfg.MODEL.ACT_DTYPE = dtype
     with contextlib.redirect_stdout(io.StringIO()):
         m = deepv3.MRFPPlus(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))

@@ -104,7 +104,7 @@ def test_multi_resolution_injection_vs_oracle(trunk, size):
     from mrfp_amd import deepv3, synth
     from mrfp_amd.config import cfg
     from mrfp_amd.perturb import MultiResolutionFourier
-    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.float32
+    cfg.MODEL.ACT_DTYPE = torch.float32
     with contextlib.redirect_stdout(io.StringIO()):
         model = deepv3.MRFPPlus(19, trunk=trunk, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
     sd = synth.synth_state_dict(synth.spec_of(model.state_dict()), seed=0, residual_gain=0.3)

@@ -39,7 +39,6 @@ def relerr(a, b):
 def build_model(backend, dtype=torch.float32, cls="MRFPPlus", fuse_ce=True):
     from mrfp_amd import deepv3
     from mrfp_amd.config import cfg
-    cfg.MODEL.CONV_BACKEND = backend
     cfg.MODEL.ACT_DTYPE = dtype
     cfg.MODEL.FUSE_UPSAMPLE_CE = fuse_ce
     model = getattr(deepv3, cls)(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
@@ -213,7 +212,7 @@ def test_full_size_properties():
     from mrfp_amd.config import cfg
 
     def make(dtype):
-        cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", dtype
+        cfg.MODEL.ACT_DTYPE = dtype
         with contextlib.redirect_stdout(io.StringIO()):
             m = deepv3.MRFPPlus(19, trunk="resnet-101", criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
         m.load_state_dict(synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=0))

@@ -448,7 +448,7 @@ def test_gated_skip_gradient_equals_the_materialised_one():
     from mrfp_amd.config import cfg
     from mrfp_amd.network import Resnet
     o = ops()
-    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.bfloat16
+    cfg.MODEL.ACT_DTYPE = torch.bfloat16
     try:
         torch.manual_seed(3)
         net = Resnet.resnet50(pretrained=False, wt_layer=[0] * 7).to(DEV).train()
@@ -491,6 +491,15 @@ def test_gated_skip_gradient_equals_the_materialised_one():
             res.append(xi.grad.clone())
             assert conv.GATED_SKIP_HITS[0] == 0
         assert torch.equal(res[0], res[1])
+        # ... and a consumer the use count cannot see (a raw torch op on the alias): the convolution that owns the alias gets an
+        # untagged sum where the tagged tensor was promised and must refuse it instead of adding it as if it were masked
+        from mrfp_amd._lib import MrfpHipError
+        o.GATED_SKIP[0] = True
+        xi = xin.clone().requires_grad_(True)
+        c, alias = cv.forward_skip(xi)
+        out = bn.fused(c, relu=True, res=alias).float() + alias.float() * 2.0
+        with pytest.raises(MrfpHipError, match="without its gate"):
+            out.pow(2).mean().backward()
     finally:
         o.GATED_SKIP[0] = True
         cfg.MODEL.ACT_DTYPE = torch.float32

@@ -70,7 +70,7 @@ def test_resnet_with_wt_layer_5_and_1_runs():
     """The trunk accepts the whitening codes of the reference's wt_layer argument (Resnet.py:525-549, 166-190)."""
     from mrfp_amd.network import Resnet
     from mrfp_amd.config import cfg
-    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.float32
+    cfg.MODEL.ACT_DTYPE = torch.float32
     for wt in ([0, 0, 5, 5, 0, 0, 0], [0, 0, 1, 2, 0, 0, 0], [0, 0, 3, 0, 0, 0, 0]):
         net = Resnet.resnet18(pretrained=False, wt_layer=wt).to(DEV).train()
         out = net(torch.rand(2, 3, 64, 64, device=DEV) * 255)
@@ -173,7 +173,7 @@ def test_isw_irw_workflow_on_a_trunk_against_the_restatement():
     from mrfp_amd.config import cfg
     from mrfp_amd.network import Resnet, cov_settings as cs
     from oracle import mrfp_oracle as orc
-    cfg.MODEL.CONV_BACKEND, cfg.MODEL.ACT_DTYPE = "hip", torch.float32
+    cfg.MODEL.ACT_DTYPE = torch.float32
     torch.manual_seed(5)
     net = Resnet.resnet18(pretrained=False, wt_layer=[0, 0, 2, 1, 0, 0, 0]).to(DEV).train()
     layers, kinds = cs.build_cov_matrix_layers([0, 0, 2, 1, 0, 0, 0], [0, 0, 64, 64, 128, 256, 512], relax_denom=0, clusters=3)

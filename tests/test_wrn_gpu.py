@@ -29,7 +29,6 @@ def relerr(a, b):
 def _trunk(sd, dtype=torch.float32):
     from mrfp_amd.config import cfg
     from mrfp_amd.network import wider_resnet
-    cfg.MODEL.CONV_BACKEND = "hip"
     cfg.MODEL.ACT_DTYPE = dtype
     m = wider_resnet.wider_resnet38_a2(classes=0, dilation=True)
     m.load_state_dict(sd)
@@ -93,7 +92,6 @@ def test_mrfp_plus_on_wrn38_vs_live_oracle(dtype, tol):
     from mrfp_amd import deepv3
     from mrfp_amd.config import cfg
     from mrfp_amd.network import wider_resnet
-    cfg.MODEL.CONV_BACKEND = "hip"
     cfg.MODEL.ACT_DTYPE = dtype
     with contextlib.redirect_stdout(io.StringIO()):
         model = deepv3.MRFPPlus(19, trunk="wider_resnet38_a2", criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
