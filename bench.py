@@ -452,6 +452,10 @@ def step_roofline(model, trainer, x, y, args):
         for k in ("ms", "tflop", "gbytes", "bound_ms"):
             g[k] = round(g[k], 3)
     roof["by_class"] = by_class
+    att = attainable(peak_f)
+    if att is not None:
+        roof["attainable"] = att
+        roof["frac_of_attainable"] = round(ach / att["mfma_tflops"], 4)
     pmc = measured_traffic(args)
     roof.update(pmc.get("conv", {}))
 
@@ -463,6 +467,8 @@ def step_roofline(model, trainer, x, y, args):
         e = {"bound": "hbm", "family": fam, "kernel": what, "launches": fam_n.get(fam, 0), "ms": round(ms, 3),
              "bytes": round(by), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
              "traffic": None}
+        if att is not None:
+            e["frac_of_attainable"] = round(gbs / att["hbm_gbs"], 4)
         e.update(pmc.get(fam, {}))
         return e
     roof["hbm"] = hbm_entry("normalisation", "stats_kernel + *_finalize_kernel + affine_fwd/bwd_kernel + copy_channels_kernel")
@@ -470,6 +476,28 @@ def step_roofline(model, trainer, x, y, args):
         roof["fourier"] = hbm_entry("fourier", "fft_rows / fft_cols_mix / dft_rows_inv kernels of mrfp_fourier_mix (3 planes per call)")
     roof["other_ms_per_step"] = round(fam_ms.get("other", 0.0), 3)
     return roof
+
+
+def attainable(peak_f):
+    """What the part can reach under this load, next to the nominal peaks: the in-kernel clock of the convolution kernels (measured
+    with a diagnostic build that stamps s_memtime / s_memrealtime around every workgroup's main loop, tools/clock_stamp.py ->
+    the newest profiles/r*_clock.json; MI355X_MICROARCH.md, DVFS give-back: the chip holds ~1.8 GHz, not 2.4, under an MFMA-dense
+    load), the MFMA rate at that clock, and the HBM bandwidth a streaming kernel achieves (the guide's ~6.3 TB/s of the 8 TB/s
+    spec).  Counters and stamps cannot be collected from inside this process: the file names what it was measured on."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_clock.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            c = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ghz = c.get("clock_ghz_median")
+    if not ghz:
+        return None
+    return {"clock_ghz": ghz, "nominal_clock_ghz": 2.4, "mfma_tflops": round(peak_f * ghz / 2.4, 1), "hbm_gbs": 6300.0,
+            "source": "profiles/" + os.path.basename(files[-1])}
 
 
 def running_commit():

@@ -259,6 +259,11 @@ int mrfp_conv_fwd_gated(const void* x, const void* wpack, const float* bias, voi
                         int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,
                         int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil,
                         int64_t sstride, const void* addend, const void* addend_mask, void* stream);
+/* Diagnostic (no reference counterpart): in a library built with -DMRFP_CLOCK_STAMP=1 (tools/clock_stamp.py; never the product
+ * build, where this returns -1) every convolution workgroup records d(s_memtime) and d(s_memrealtime) around its main loop; out
+ * receives n pairs {shader cycles, 100 MHz ticks} of the LAST launch of `family` (0: conv_igemm, 1: pointwise, 2: wgrad).
+ * In-kernel clock = cycles / ticks x 100 MHz (MI355X_MICROARCH.md, DVFS give-back). */
+int mrfp_debug_clock_stamps(int family, uint64_t* out, int64_t n);
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q);
 int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype,
                     int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ctrue, int64_t N, int64_t ldn,

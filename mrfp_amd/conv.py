@@ -218,9 +218,17 @@ _WG_EXPECT = {}             # launch geometry -> problems seen in the last compl
 _WG_SEEN = {}               # ... in the running one
 
 
+_DEBUG_SKIP_WGRAD = _os.environ.get("MRFP_DEBUG_SKIP_WGRAD") == "1"     # timing diagnostics only: weight gradients are NOT computed
+
+
 def _issue_wgrads(sig, items):
     """One mrfp_conv_wgrad(_grouped) launch for `items` (same geometry) on the weight-gradient stream (or the current one)."""
     import ctypes
+    if _DEBUG_SKIP_WGRAD:
+        for _, _, _, weight in items:
+            GRAD_DEFERRED.discard(id(weight))
+            notify_grad(weight)
+        return
     (dtype, B, H, W, Cphys, C, N, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil) = sig
     x0 = items[0][0]
     M, Q = B * Ho * Wo, R * S * Cphys
@@ -271,7 +279,7 @@ def flush_wgrads(sig=None):
 
 def _queue_wgrad(sig, x, dy, sink, weight):
     if _GROUP_MAX[0] is None:
-        _GROUP_MAX[0] = int(_lib.lib().mrfp_conv_wgrad_group_max())
+        _GROUP_MAX[0] = min(int(_lib.lib().mrfp_conv_wgrad_group_max()), int(_os.environ.get("MRFP_WGRAD_GROUP_MAX", "32")))
     if not _JOIN_QUEUED[0]:       # when this backward pass ends: flush every queue, then the caller's stream waits for the side stream
         _JOIN_QUEUED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(_join_at_end_of_backward)

@@ -12,7 +12,47 @@
 #define MRFP_VMCNT0 0
 #endif
 
+// MRFP_CLOCK_STAMP (diagnostic build only, default off; tools/clock_stamp.py builds libmrfp_hip_clk.so with it): every convolution
+// workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) once at its start and once before its epilogue and
+// writes the two differences to a buffer of its own that nothing else reads -- in-kernel clock = d(memtime) / d(memrealtime) x
+// 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  In the product build no stamp executes.
+#ifndef MRFP_CLOCK_STAMP
+#define MRFP_CLOCK_STAMP 0
+#endif
+
 namespace mrfp {
+
+constexpr int kStampSlots = 4096;
+#if MRFP_CLOCK_STAMP
+struct ClockStamp {
+    unsigned long long t0, r0;
+    __device__ __forceinline__ void begin() {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone: the loop's own LDS waits stay counted
+    }
+    __device__ __forceinline__ void end(unsigned long long (*buf)[2]) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (threadIdx.x == 0) {
+            buf[blockIdx.x % kStampSlots][0] = t1 - t0;
+            buf[blockIdx.x % kStampSlots][1] = r1 - r0;
+        }
+    }
+};
+#define MRFP_STAMP_DECL(name) __device__ unsigned long long name[::mrfp::kStampSlots][2];
+#define MRFP_STAMP_BEGIN() ::mrfp::ClockStamp stamp__; stamp__.begin()
+#define MRFP_STAMP_END(name) stamp__.end(name)
+#define MRFP_STAMP_READ(name, out, n) (hipMemcpyFromSymbol(out, HIP_SYMBOL(name), (size_t)(n) * 16) == hipSuccess ? 0 : -1)
+#else
+#define MRFP_STAMP_DECL(name)
+#define MRFP_STAMP_BEGIN()
+#define MRFP_STAMP_END(name)
+#define MRFP_STAMP_READ(name, out, n) (-1)
+#endif
+int stamps_igemm(unsigned long long* out, int n);     // conv_igemm.hip
+int stamps_pw(unsigned long long* out, int n);        // conv_pw.hip
+int stamps_wgrad(unsigned long long* out, int n);     // conv_wgrad.hip
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

@@ -27,6 +27,9 @@
 
 namespace mrfp {
 
+MRFP_STAMP_DECL(g_stamps_igemm)
+int stamps_igemm(unsigned long long* out, int n) { return MRFP_STAMP_READ(g_stamps_igemm, out, n); }
+
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int TM, int TN, bool RR = false>
 __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -34,6 +37,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA0 = smem;
     char* const sB0 = smem + BM * 128;
+    MRFP_STAMP_BEGIN();
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
         }
     }
 
+    MRFP_STAMP_END(g_stamps_igemm);
     // epilogue.  MFMA 32x32 accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31], i.e. a
     // lane owns single elements of 16 rows -- storing that directly is 2-byte scattered traffic.  Instead every
     // wave transposes its tile through LDS (free after the K loop) 32 rows at a time and writes whole 16-byte
@@ -718,6 +723,18 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
                            (hipStream_t)stream, colstats, (int)nblk, C2);
         MRFP_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+/* diagnostic: the clock stamps of the last launch of a kernel family (0: conv_igemm, 1: pointwise, 2: wgrad) -- only in a
+ * library built with -DMRFP_CLOCK_STAMP=1 (tools/clock_stamp.py); the product build returns -1 */
+int mrfp_debug_clock_stamps(int family, uint64_t* out, int64_t n) {
+    MRFP_CHECK(MRFP_CLOCK_STAMP != 0, "clock stamps: not a diagnostic build (-DMRFP_CLOCK_STAMP=1)");
+    MRFP_CHECK(out && n > 0 && n <= kStampSlots && family >= 0 && family <= 2, "clock stamps: bad arguments");
+    hipDeviceSynchronize();
+    const int rc = family == 0 ? stamps_igemm((unsigned long long*)out, (int)n)
+                   : family == 1 ? stamps_pw((unsigned long long*)out, (int)n) : stamps_wgrad((unsigned long long*)out, (int)n);
+    MRFP_CHECK(rc == 0, "clock stamps: read-back failed");
     return 0;
 }
 

@@ -37,6 +37,9 @@ struct BsP {
 
 struct HasPrev { static constexpr bool value = true; };
 struct NoPrev { static constexpr bool value = false; };
+MRFP_STAMP_DECL(g_stamps_pw)
+int stamps_pw(unsigned long long* out, int n) { return MRFP_STAMP_READ(g_stamps_pw, out, n); }
+
 template <typename T, int KB, int NST, bool STATS, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     constexpr int ROWB = KB * 128;              // bytes of one row of X (K elements)
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     const int t0 = chunk * per, t1 = min(p.tiles, t0 + per);
     if (t0 >= t1) return;
     const int n0 = panel * 128 + wave * 32;     // this wave's 32 columns
+    MRFP_STAMP_BEGIN();
 
     // ---- X tile DMA: piece q of this wave covers block kb = q / 2, rows (q & 1) * 32 + wave * 8 .. + 7 --------------------
     unsigned src[NP], dst[NP];
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) epilogue_part(t1 - 1, i, accA, avA, amA);
     }
+    MRFP_STAMP_END(g_stamps_pw);
     if constexpr (STATS) {
         // ONE statistics row block per workgroup range (all its tiles): the 16 lanes of a quarter hold the same 8 channels
         // for 16 different pixels -- fold them (DPP, fixed order) and let lane 0 of the quarter write

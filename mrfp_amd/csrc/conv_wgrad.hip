@@ -14,6 +14,9 @@
 // =============================================================================================
 namespace mrfp {
 
+MRFP_STAMP_DECL(g_stamps_wgrad)
+int stamps_wgrad(unsigned long long* out, int n) { return MRFP_STAMP_READ(g_stamps_wgrad, out, n); }
+
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((address_space(3))) short4v lds_short4v;
 
@@ -117,6 +120,9 @@ template <> struct WgFrag<float> {
 #ifndef MRFP_WGRAD_HOLD
 #define MRFP_WGRAD_HOLD 2      // k steps (of 4 per K' tile) multiplied after the next tile's transfer has been issued
 #endif
+#ifndef MRFP_WGRAD_HOLD_BIG
+#define MRFP_WGRAD_HOLD_BIG 2  // the same for the 256 x 128 tile
+#endif
 template <typename T> struct WgTile { static constexpr int BKP = 64; };   // pixels per K' tile
 template <> struct WgTile<float> { static constexpr int BKP = 32; };
 
@@ -124,19 +130,25 @@ template <> struct WgTile<float> { static constexpr int BKP = 32; };
 // by a constant and need no (ih, iw) bookkeeping -- 60 of the 85 VALU and 40 of the 64 SALU instructions of a K' tile in
 // the general kernel, on layers (M = 36 864 bottleneck 1x1) that are bound by exactly that instruction stream
 // (profiles/r02_experiments.md section 4: 31 us with or without any global traffic, MFMA time 11 us).
-template <typename T, int WM, int WN, bool DMA, bool DENSE = false>
-__global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, WgGroup grp) {   // 2nd = waves per SIMD
+// TMB: 32-row accumulator blocks per wave along the output channels.  2 = the 128 x 128 workgroup tile (64 FLOP per fill byte, four
+// workgroups per CU); 4 = a 256 x 128 tile (85 FLOP per fill byte, 6 fragment reads per 8 MFMAs instead of 4 per 4; 128 accumulator
+// registers, two workgroups per CU) for the layers with N % 256 == 0 and long K' loops -- the grouped launches above all.
+template <typename T, int WM, int WN, bool DMA, bool DENSE = false, int TMB = 2>
+__global__ __launch_bounds__(256, (TMB == 4 ? 2 : DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, WgGroup grp) {   // 2nd = waves per SIMD
     static_assert(WM * WN == 4, "4 waves");
     static_assert(!DMA || sizeof(T) == 2, "LDS-DMA layout is for the 16-bit types");
+    static_assert(TMB == 2 || (TMB == 4 && DMA && WM == 2), "the 256 x 128 tile is an LDS-DMA kernel");
     constexpr int BKP = WgTile<T>::BKP;
     constexpr int EPC = 16 / (int)sizeof(T);                 // elements per 16-byte chunk
-    constexpr int CY = 64 * WM / EPC, CX = 64 * WN / EPC;    // chunks per tile row
+    constexpr int BNN = 32 * TMB * WM;                       // output channels per workgroup tile
+    constexpr int CY = BNN / EPC, CX = 64 * WN / EPC;        // chunks per tile row
     constexpr int SY = BKP * CY / 256, SX = BKP * CX / 256;  // slots per thread
-    constexpr int PY = 64 * WM * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);   // row pitches
-    constexpr int NBY = 2 * WM, NBX = 2 * WN;                 // 64-byte blocks per row (DMA layout)
+    constexpr int PY = BNN * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);   // row pitches
+    constexpr int NBY = BNN * (int)sizeof(T) / 64, NBX = 2 * WN;    // 64-byte blocks per row (DMA layout)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ty = smem;               // single LDS buffer: the next tile waits in registers
     char* const tx = smem + BKP * PY;
+    MRFP_STAMP_BEGIN();
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, W
         dybase = grp.dy[prob];
     }
     const int split = work / p.tiles, tile = work - split * p.tiles;
-    const int n0 = (tile / ntq) * 64 * WM, q0 = (tile % ntq) * 64 * WN;
+    const int n0 = (tile / ntq) * BNN, q0 = (tile % ntq) * 64 * WN;
     const int kbeg = split * p.klen;
     const int kend = min(p.M, kbeg + p.klen);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, (int)p.xbytes, 0x00020000);
@@ -250,9 +262,9 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, W
         for (int i = 0; i < SX; ++i) *reinterpret_cast<uint4*>(tx + (xrow + i * (256 / CX)) * PX + xchunk * 16) = rx[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TMB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -267,28 +279,28 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, W
         // EARLY ISSUE (as in conv_igemm_kernel): the fragments of the last HOLD k steps go to registers, a barrier frees the
         // buffer, the next tile's transfer is issued and the held k steps are multiplied inside its latency.
         constexpr int KSN = BKP / 16;
-        constexpr int HOLD = (!DENSE && WM == 1) ? 1 : MRFP_WGRAD_HOLD;     // (the 64x256 gather variant spills with two held k steps)
+        constexpr int HOLD = (!DENSE && WM == 1) ? 1 : TMB == 4 ? MRFP_WGRAD_HOLD_BIG : MRFP_WGRAD_HOLD;     // (the 64x256 gather variant spills with two held k steps)
         if (nkt > 0) load_tile(kbeg, ry, rx);
         for (int kt = 0; kt < nkt; ++kt) {
             dma_wait<0>();            // explicit: across the back edge the compiler's own wait lands behind the barrier
             __syncthreads();          // the tile has landed everywhere
 #pragma unroll
             for (int ks = 0; ks < KSN - HOLD; ++ks) {
-                uint4 fa[2], fb[2];
+                uint4 fa[TMB], fb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = wg_read_sw<NBY>(ty, wm * 64 + i * 32, ks * 16, lane);
+                for (int i = 0; i < TMB; ++i) fa[i] = wg_read_sw<NBY>(ty, wm * 32 * TMB + i * 32, ks * 16, lane);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[j] = wg_read_sw<NBX>(tx, wn * 64 + j * 32, ks * 16, lane);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TMB; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
             }
-            uint4 ha[HOLD > 0 ? HOLD : 1][2], hb[HOLD > 0 ? HOLD : 1][2];
+            uint4 ha[HOLD > 0 ? HOLD : 1][TMB], hb[HOLD > 0 ? HOLD : 1][2];
 #pragma unroll
             for (int h = 0; h < HOLD; ++h) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) ha[h][i] = wg_read_sw<NBY>(ty, wm * 64 + i * 32, (KSN - HOLD + h) * 16, lane);
+                for (int i = 0; i < TMB; ++i) ha[h][i] = wg_read_sw<NBY>(ty, wm * 32 * TMB + i * 32, (KSN - HOLD + h) * 16, lane);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) hb[h][j] = wg_read_sw<NBX>(tx, wn * 64 + j * 32, (KSN - HOLD + h) * 16, lane);
             }
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, W
 #pragma unroll
             for (int h = 0; h < HOLD; ++h)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TMB; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], ha[h][i], hb[h][j]);
         }
@@ -327,6 +339,7 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, W
     }
     }
 
+    MRFP_STAMP_END(g_stamps_wgrad);
     float* out = p.slab + ((size_t)prob * p.splits + split) * p.N * p.Q;
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -334,10 +347,10 @@ __global__ __launch_bounds__(256, (DMA ? 4 : 3)) void conv_wgrad_kernel(WgP p, W
         const int qq = q0 + wn * 64 + j * 32 + lr;
         if (qq >= p.Q) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMB; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int n = n0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int n = n0 + wm * 32 * TMB + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (n < p.N) out[(size_t)n * p.Q + qq] = acc[i][j][e];
             }
     }
@@ -402,69 +415,116 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (c + 3 < Ctrue) d[3 * RS] = acc.w;
 }
 
-template <typename T, int WM, int WN, bool DMA, bool DENSE = false>
+template <typename T, int WM, int WN, bool DMA, bool DENSE = false, int TMB = 2>
 static int launch_wgrad_v(const WgP& p, int splits, hipStream_t st, const WgGroup* grp) {
-    constexpr int PY = 64 * WM * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);
+    constexpr int BNN = 32 * TMB * WM;
+    constexpr int PY = BNN * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);
     const int lds = WgTile<T>::BKP * (PY + PX);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN, DMA, DENSE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN, DMA, DENSE, TMB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     WgP q = p;
-    q.tiles = ((p.N + 64 * WM - 1) / (64 * WM)) * ((p.Q + 64 * WN - 1) / (64 * WN));
+    q.tiles = ((p.N + BNN - 1) / BNN) * ((p.Q + 64 * WN - 1) / (64 * WN));
     q.splits = splits;
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, DMA, DENSE>), dim3((unsigned)(q.tiles * splits * q.ngroup)), dim3(256), lds, st, q, *grp);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, DMA, DENSE, TMB>), dim3((unsigned)(q.tiles * splits * q.ngroup)), dim3(256), lds, st, q, *grp);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
 
 // MRFP_WGRAD_DMA=0 keeps register staging for the 16-bit types (A/B measurements); fp32 always stages in registers
 template <typename T, int WM, int WN>
-static int launch_wgrad(const WgP& p, int splits, hipStream_t st, const WgGroup* grp) {
+static int launch_wgrad(const WgP& p, int splits, hipStream_t st, const WgGroup* grp, int tmb = 2) {
     static int dma = -1;
     if (dma < 0) { const char* e = getenv("MRFP_WGRAD_DMA"); dma = e ? atoi(e) : 1; }
     if (sizeof(T) == 2 && dma) {
         static int dense = -1;
         if (dense < 0) { const char* e = getenv("MRFP_WGRAD_DENSE"); dense = e ? atoi(e) : 1; }
         const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && p.H == p.Ho && p.W == p.Wo;
+        if constexpr (WM == 2 && sizeof(T) == 2) {
+            if (tmb == 4) {
+                if (dense && pointwise) return launch_wgrad_v<T, WM, WN, true, true, 4>(p, splits, st, grp);
+                return launch_wgrad_v<T, WM, WN, true, false, 4>(p, splits, st, grp);
+            }
+        }
         if (dense && pointwise) return launch_wgrad_v<T, WM, WN, sizeof(T) == 2, true>(p, splits, st, grp);
         return launch_wgrad_v<T, WM, WN, sizeof(T) == 2>(p, splits, st, grp);
     }
     return launch_wgrad_v<T, WM, WN, false>(p, splits, st, grp);
 }
 
-static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen, int64_t cap = 0, int64_t group = 1) {
-    wm = N <= 64 ? 1 : 2;
-    const int wn = 4 / wm;
-    // (a grouped launch: `group` problems of this geometry fill the chip together; the split count is per problem)
-    const int64_t tiles = group * ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
-    const int64_t nkt = (M + bkp - 1) / bkp;
-    // Split count from a small cost model (times in us, constants fitted to the bench workload's per-launch timings):
-    //   a CU that holds w = ceil(tiles*sp/256) workgroups needs w * (K' tiles per split) tile-steps of ~0.84 us, divided
-    //   by a latency-hiding efficiency (1 workgroup per CU 0.6, 2 -> 0.85, >= 3 -> 1); every split adds an fp32 slab of dW
-    //   that is written once and read once by the reduction (~3 TB/s).
-    // MRFP_WGRAD_WGS=<n> replaces the model by "about n workgroups" (A/B measurements).
+// MRFP_WGRAD_BIG: 0 = never the 256 x 128 tile, 1 (default) = where the cost model prefers it, 2 = wherever it is legal (A/B runs)
+static int wgrad_big_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("MRFP_WGRAD_BIG");
+        mode = e ? atoi(e) : 1;
+        const char* d = getenv("MRFP_WGRAD_DMA");      // (=0: the register-staged A/B path of the 16-bit kernels has no 256 x 128 instance)
+        if (d && atoi(d) == 0) mode = 0;
+    }
+    return mode;
+}
+
+// Split count from a small cost model (times in us, constants fitted to the bench workload's per-launch timings):
+//   a CU that holds w = ceil(tiles*sp/256) workgroups needs w * (K' tiles per split) tile-steps of `step` us, divided
+//   by a latency-hiding efficiency (fewer co-resident workgroups than the kernel's occupancy hide less of each other's fill
+//   latency); every split adds an fp32 slab of dW that is written once and read once by the reduction (~3 TB/s).
+// MRFP_WGRAD_WGS=<n> replaces the model by "about n workgroups" (A/B measurements).
+static double wgrad_cost(int64_t tiles, int64_t nkt, int64_t group, double nq, double step, int occ, int64_t& sp_out) {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("MRFP_WGRAD_WGS");
         target = e ? atoi(e) : 0;
     }
     int64_t sp = 1;
+    double best = 1e30;
     if (target > 0) {
         sp = target / tiles;
     } else {
-        double best = 1e30;
         int64_t smax = 1024 / tiles > 96 ? 1024 / tiles : 96;      // few tiles: enough splits to fill the chip
         if (smax > nkt) smax = nkt;
         for (int64_t c = 1; c <= smax; ++c) {
             const int64_t w = (tiles * c + 255) / 256, iters = (nkt + c - 1) / c;
-            const double eff = w >= 3 ? 1.0 : w == 2 ? 0.85 : 0.6;
-            const double cost = (double)w * (double)iters * 0.84 / eff + (double)c * (double)group * ((double)N * (double)Q * 8.0 / 3.0e6);
+            const double eff = occ == 4 ? (w >= 3 ? 1.0 : w == 2 ? 0.85 : 0.6) : (w >= 2 ? 1.0 : 0.7);
+            const double cost = (double)w * (double)iters * step / eff + (double)c * (double)group * (nq * 8.0 / 3.0e6);
             if (cost < best * 0.999) { best = cost; sp = c; }
         }
     }
+    sp_out = sp;
+    return best;
+}
+
+// wm: wave rows (1: the 64 x 256 tile for N <= 64; 2: 128 x 128 or, tmb = 4, 256 x 128); splits / klen: K' splits and pixels per split
+static void wgrad_plan(int64_t M, int64_t N, int64_t Q, int bkp, int& wm, int& splits, int& klen, int64_t cap = 0, int64_t group = 1,
+                       int* tmb_out = nullptr, bool pointwise = false) {
+    wm = N <= 64 ? 1 : 2;
+    const int wn = 4 / wm;
+    // (a grouped launch: `group` problems of this geometry fill the chip together; the split count is per problem)
+    const int64_t tiles = group * ((N + 64 * wm - 1) / (64 * wm)) * ((Q + 64 * wn - 1) / (64 * wn));
+    const int64_t nkt = (M + bkp - 1) / bkp;
+    int64_t sp = 1;
+    (void)wgrad_cost(tiles, nkt, group, (double)N * (double)Q, 0.84, 4, sp);
+    int tmb = 2;
+    // The 256 x 128 tile: 16-bit LDS-DMA kernels (K' tile of 64 pixels), whole 256-channel tiles.  Two workgroups per CU hide less
+    // fill latency than four, so it needs LONG K' loops to pay -- measured per launch class of the bench step (tools/wgrad_micro.py,
+    // MRFP_WGRAD_BIG=0 / 2, same box): the grouped layer-3 pointwise launches 28.7 -> 26.0 us per problem, 512 <-> 2048 grouped
+    // 88 -> 83-86, the 3x3 layers at 192^2 697 -> 634 and 890 -> 802 us; but single pointwise launches with few tiles 37 -> 44 us
+    // (every split gets ~10 K' tiles), and the 3x3 layers at 48^2 47.2 -> 49.2 us per problem even grouped.  Rule: enough K' tile-steps
+    // per CU (`load`, in 256 x 128 units), and for the gather (non-pointwise) form only the large images.
+    if (bkp == 64 && wm == 2 && N % 256 == 0 && wgrad_big_mode() > 0) {
+        const int64_t tiles4 = group * (N / 256) * ((Q + 127) / 128);
+        const int64_t load = tiles4 * nkt / 256;
+        const bool want = load >= 100 && (pointwise || M >= 65536);
+        if (wgrad_big_mode() >= 2 || want) {
+            int64_t sp4 = 1;
+            (void)wgrad_cost(tiles4, nkt, group, (double)N * (double)Q, 1.30, 2, sp4);
+            tmb = 4;
+            sp = sp4;
+        }
+    }
+    if (tmb_out) *tmb_out = tmb;
     if (sp < 1) sp = 1;
     if (sp > nkt) sp = nkt;
     if (cap > 0 && sp > cap) sp = cap;         // (a batch range of a larger call: the workspace was sized for the whole call)
@@ -482,8 +542,11 @@ extern "C" {
 
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q) {
     int wm, s32, s64, klen;
+    int s64p;
     mrfp::wgrad_plan(M, N, Q, 32, wm, s32, klen);         // fp32 K' tile
     mrfp::wgrad_plan(M, N, Q, 64, wm, s64, klen);         // bf16 K' tile
+    mrfp::wgrad_plan(M, N, Q, 64, wm, s64p, klen, 0, 1, nullptr, true);      // ... of a pointwise launch (its tile rule differs)
+    if (s64p > s64) s64 = s64p;
     return (int64_t)(s32 > s64 ? s32 : s64) * N * Q * 4;
 }
 
@@ -528,7 +591,8 @@ static int wgrad_run(const void* const* xs, const void* const* dys, float* const
     p.div_hw = make_fastdiv((unsigned)(Ho * Wo)); p.div_w = make_fastdiv((unsigned)Wo);
     hipStream_t st = (hipStream_t)stream;
     int wm0, cap, klen0;
-    wgrad_plan(B * Ho * Wo, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm0, cap, klen0, 0, count);     // what `ws` was sized for
+    const bool pointwise = R == 1 && S == 1 && stride == 1 && pad_h == 0 && pad_w == 0 && H == Ho && W == Wo;
+    wgrad_plan(B * Ho * Wo, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm0, cap, klen0, 0, count, nullptr, pointwise);     // what `ws` was sized for
     for (int64_t b0 = 0; b0 < B; b0 += bmax) {
         const int64_t bc = B - b0 < bmax ? B - b0 : bmax;
         p.B = (int)bc;
@@ -537,12 +601,12 @@ static int wgrad_run(const void* const* xs, const void* const* dys, float* const
         p.dy = (const char*)dys[0] + b0 * yimg;
         p.xbytes = (dbg_drop & 1) ? 0u : (unsigned)(bc * ximg);
         p.dybytes = (dbg_drop & 2) ? 0u : (unsigned)(bc * yimg);
-        int wm, splits;
-        wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen, cap, count);
+        int wm, splits, tmb = 2;
+        wgrad_plan(p.M, N, p.Q, dtype == MRFP_F32 ? 32 : 64, wm, splits, p.klen, cap, count, &tmb, pointwise);
         int rc;
         if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st, &grp) : launch_wgrad<float, 2, 2>(p, splits, st, &grp);
-        else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st, &grp) : launch_wgrad<f16, 2, 2>(p, splits, st, &grp);
-        else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st, &grp) : launch_wgrad<bf16, 2, 2>(p, splits, st, &grp);
+        else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st, &grp) : launch_wgrad<f16, 2, 2>(p, splits, st, &grp, tmb);
+        else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st, &grp) : launch_wgrad<bf16, 2, 2>(p, splits, st, &grp, tmb);
         if (rc) return rc;
         const int64_t total4 = N * (int64_t)p.Q / 4;          // Q = R*S*C and C*esz % 16 == 0  =>  Q % 4 == 0
         const int64_t blocks = (total4 + 63) / 64;
@@ -563,8 +627,11 @@ int64_t mrfp_conv_wgrad_group_max(void) { return kWgMaxGroup; }
 
 int64_t mrfp_conv_wgrad_grouped_ws_bytes(int64_t M, int64_t N, int64_t Q, int64_t count) {
     int wm, s32, s64, klen;
+    int s64p;
     mrfp::wgrad_plan(M, N, Q, 32, wm, s32, klen, 0, count);
     mrfp::wgrad_plan(M, N, Q, 64, wm, s64, klen, 0, count);
+    mrfp::wgrad_plan(M, N, Q, 64, wm, s64p, klen, 0, count, nullptr, true);
+    if (s64p > s64) s64 = s64p;
     return (int64_t)(s32 > s64 ? s32 : s64) * count * N * Q * 4;
 }
 

