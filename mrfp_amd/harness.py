@@ -381,7 +381,10 @@ class Trainer:
                 # capture on the warm-up's stream, with the warm-up's autograd graph gone (.detach() above): a gradient
                 # accumulator that remembers another stream makes autograd fork / join the capture once per parameter, and
                 # the replay of such a graph pays a cross-queue barrier per fork (35 vs 15 ms on ResNet-50 8x512^2)
-                g = torch.cuda.CUDAGraph()
+                g = torch.cuda.CUDAGraph(keep_graph=True)       # (the hipGraph_t stays readable: graph_topology())
+                if getattr(self, "_debug_capture_on_fresh_stream", False):      # tools/graph_dbg.py only: the round-2 capture, for evidence
+                    side = torch.cuda.Stream()
+                    side.wait_stream(self._graph_stream)
                 with torch.cuda.graph(g, stream=side):
                     static_loss = self._fwd_bwd(static_img, static_lab).detach()    # only the value is read at replay: no autograd graph
                                                                                       # (and its accumulator nodes) kept alive per key
@@ -402,6 +405,34 @@ class Trainer:
                 m._nbt_pending += 1
         self.opt.step(1.0 / self.loss_scale)
         return static_loss
+
+
+def graph_topology(g):
+    """Nodes / dependency edges of a captured torch.cuda.CUDAGraph(keep_graph=True) read back through the HIP runtime
+    (hipGraphGetNodes / hipGraphGetEdges): {"nodes", "edges", "forks" (nodes with more than one successor), "joins" (more than
+    one predecessor), "roots"}.  A capture that stayed on ONE stream is a chain: forks == joins == 0, one root.  Every stream the
+    capture forked to shows up as a fork / join pair -- and each pair becomes a cross-queue dependency at replay (the round-2
+    capture had one pair per parameter: see DESIGN.md section 5)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    graph = ctypes.c_void_p(int(g.raw_cuda_graph()))
+    n = ctypes.c_size_t(0)
+    hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    hip.hipGraphGetEdges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    if hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) != 0:
+        raise _lib.MrfpHipError("hipGraphGetNodes failed")
+    e = ctypes.c_size_t(0)
+    if hip.hipGraphGetEdges(graph, None, None, ctypes.byref(e)) != 0:
+        raise _lib.MrfpHipError("hipGraphGetEdges failed")
+    src, dst = (ctypes.c_void_p * max(1, e.value))(), (ctypes.c_void_p * max(1, e.value))()
+    if e.value and hip.hipGraphGetEdges(graph, src, dst, ctypes.byref(e)) != 0:
+        raise _lib.MrfpHipError("hipGraphGetEdges failed")
+    out_deg, in_deg = {}, {}
+    for i in range(e.value):
+        out_deg[src[i]] = out_deg.get(src[i], 0) + 1
+        in_deg[dst[i]] = in_deg.get(dst[i], 0) + 1
+    return {"nodes": int(n.value), "edges": int(e.value), "forks": sum(1 for v in out_deg.values() if v > 1),
+            "joins": sum(1 for v in in_deg.values() if v > 1), "roots": int(n.value) - len(in_deg)}
 
 
 @torch.no_grad()

@@ -280,6 +280,8 @@ class _BatchNormAct(torch.autograd.Function):
         # convolution's dgrad epilogue only, which can apply the gate itself -- backward then hands it the incoming
         # gradient as it is, with the mask attached, instead of writing dy * [y > 0]
         ctx.gate_skip = bool(ctx.ymask and GATED_SKIP[0] and getattr(res, "_mrfp_skip_alias", False))
+        # this layer itself can take a gated gradient: plain BatchNorm (no ReLU, no residual, no resize), 16-bit, whole mask bytes
+        ctx.gate_ok = bool(not relu and res is None and plan is None and training and x.element_size() == 2 and C % 8 == 0)
         # ... provided this tail stays the alias's ONLY consumer: with a second one autograd sums the two gradients into a fresh,
         # untagged tensor and the unmasked one would be used as if it were masked.  Every operator of this layer counts its use
         # of the alias (_chk); the count is read in backward, when the whole forward has run.
@@ -298,11 +300,35 @@ class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, w32, mean, invstd, A, S = ctx.saved_tensors
+        # A residual tail may hand this layer its incoming gradient UNMASKED with its sign mask attached (this layer is the
+        # BatchNorm of a downsample branch: reference Resnet.py:209-212 `residual = self.downsample(x)`; batch_norm_act() marked
+        # its output as able to take that): the two passes below then gate dy while they read it, and dy * [out > 0] of the tail
+        # is never written.  As in conv._Conv2d.backward: if the gate was promised and something else arrives, fail loudly.
+        gate = None
+        cell = getattr(ctx, "_mrfp_cell", None)
+        g = getattr(dy, "_mrfp_gate", None)
+        if cell is not None and cell[1]:
+            if g is None or g[1] != dy._version:
+                raise _lib.MrfpHipError("a gated gradient reached its BatchNorm without its gate: the layer's output was also "
+                                        "consumed by an operator outside mrfp_amd.ops (set MRFP_GATED_SKIP=0)")
+            cell[1] = False
+        if g is not None:
+            if (g[1] == dy._version and ctx.gate_ok and dy.dtype == x.dtype and dy.shape == x.shape
+                    and dy.is_contiguous(memory_format=CL)):
+                gate = g[0]
+            else:
+                from .conv import ungate
+                dy = ungate(dy)
         dy = _chk(dy, "dy")
         plan = ctx.plan
         B, Ho, Wo, C, *_ = _geom(x, plan)
         fA, fS = (A, S) if ctx.remask else (None, None)
-        if ctx.ymask:                      # y holds the sign mask
+        if gate is not None:               # plain BatchNorm behind a gated gradient: the tail's sign mask is the ReLU gate
+            nslab, ws = _stats_ws(B, Ho, C, x.device)
+            call("mrfp_stats_bwd_mask", ptr(dy), ptr(x), ptr(gate), ptr(mean), 0, dt(x), B, Ho, Wo, C, ptr(ws), stream())
+            nb_ = B
+            GATED_BN_HITS[0] += 1
+        elif ctx.ymask:                    # y holds the sign mask
             nslab, ws = _stats_ws(B, Ho, C, x.device)
             call("mrfp_stats_bwd_mask", ptr(dy), ptr(x), ptr(y), ptr(mean), 0, dt(x), B, Ho, Wo, C, ptr(ws), stream())
             nb_ = B
@@ -326,7 +352,12 @@ class _BatchNormAct(torch.autograd.Function):
             # gradient is just dy' * weight * invstd -- the batch-statistics terms Q, R vanish
             Q.zero_()
             R.zero_()
-        if ctx.ymask:
+        if gate is not None:
+            dx = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
+            dres = None
+            call("mrfp_affine_bwd_mask", ptr(dy), ptr(x), ptr(gate), ptr(dx), None, dt(dy), B, Ho, Wo, C, ptr(P), ptr(Q), ptr(R), 0,
+                 stream())
+        elif ctx.ymask:
             dx = empty_cl(B, C, Ho, Wo, dy.dtype, dy.device)
             if ctx.gate_skip and ctx.needs_input_grad[5] and ctx.alias_uses is not None and ctx.alias_uses[0] == 1:
                 dres = dy.view_as(dy)                  # unmasked; the consumer applies the mask (conv._Conv2d.backward / conv.ungate)
@@ -351,9 +382,21 @@ class _BatchNormAct(torch.autograd.Function):
         return dx, dw, db, None, None, dres, None, None, None, None, None
 
 
+GATED_BN_HITS = [0]        # BatchNorm backward passes that applied a residual tail's gate to their incoming gradient (tests)
+GATED_BN = [os.environ.get("MRFP_GATED_BN", "1") != "0"]      # (A/B switch for this form alone)
+
+
 def batch_norm_act(x, weight, bias, running_mean, running_var, *, training, momentum=0.1, eps=1e-5,
                    relu=False, res=None, plan=None):
-    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, res, training, momentum, eps, relu, plan)
+    y = _BatchNormAct.apply(x, weight, bias, running_mean, running_var, res, training, momentum, eps, relu, plan)
+    if (GATED_BN[0] and GATED_SKIP[0] and SIGN_MASK[0] and not relu and res is None and plan is None and training and y.grad_fn is not None
+            and y.element_size() == 2 and y.shape[1] % 8 == 0):
+        # the plain BatchNorm of a downsample branch: a residual tail that consumes this output (and nothing else does: the use
+        # count) may send its gradient gated -- see _BatchNormAct.backward.  Same protocol as a convolution's skip alias.
+        y._mrfp_skip_alias = True
+        y._mrfp_uses = [0, False]
+        y.grad_fn._mrfp_cell = y._mrfp_uses
+    return y
 
 
 # ------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ from mrfp_amd import synth
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT_DIR = os.path.dirname(HERE)
 G = np.load(os.path.join(HERE, "golden", "mrfp_c1.npz"))
 SPEC = json.load(open(os.path.join(HERE, "golden", "state_dict_spec.json")))
 
@@ -174,6 +175,42 @@ def test_graph_mode_matches_eager():
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
     assert out[0][3] == out[1][3] == 5 and torch.equal(out[0][4], out[1][4])
+    # the captured graphs are CHAINS: no fork / join pair (= no cross-stream dependency a replay would have to honour across
+    # hardware queues; the round-2 capture had one pair per parameter and crashed in hipGraphLaunch with one queue: DESIGN.md section 5)
+    from mrfp_amd.harness import graph_topology
+    assert len(tr._graphs) == 2
+    for entry in tr._graphs.values():
+        topo = graph_topology(entry[0])
+        assert topo["nodes"] > 500 and topo["forks"] == 0 and topo["joins"] == 0 and topo["roots"] == 1, topo
+
+
+def test_graph_mode_with_one_hardware_queue_in_subprocess():
+    """GPU_MAX_HW_QUEUES=1 (read by the HIP runtime at start-up: a child process): capture + three replays of the ResNet-50 step
+    must run and reproduce the eager losses bit for bit -- with the round-2 capture this configuration crashed inside
+    hipGraphLaunch."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, json, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_harness_gpu as t\n"
+        "from mrfp_amd import synth\n"
+        "from mrfp_amd.deepv3 import InjectedRandom\n"
+        "from mrfp_amd.harness import Trainer\n"
+        "x, y = synth.synth_batch(2, 128, 128, seed=3); x, y = x.cuda(), y.cuda()\n"
+        "noise = {k: v.cuda() for k, v in synth.synth_noise(2, seed=4).items()}\n"
+        "res = []\n"
+        "for graph in (False, True):\n"
+        "    model, _ = t._model(); model.train(); tr = Trainer(model, lr=1e-3)\n"
+        "    if graph: tr.enable_graph()\n"
+        "    model.rng = InjectedRandom((True, True, True), noise)\n"
+        "    res.append([float(tr.step(x, y)) for _ in range(4)])\n"
+        "torch.cuda.synchronize()\n"
+        "assert res[0] == res[1], res\n"
+        "print('ok', os.environ.get('GPU_MAX_HW_QUEUES'))\n") % (ROOT_DIR, HERE)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok 1" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

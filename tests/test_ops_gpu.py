@@ -457,6 +457,7 @@ def test_gated_skip_gradient_equals_the_materialised_one():
         for gated in (True, False):
             o.GATED_SKIP[0] = gated
             conv.GATED_SKIP_HITS[0] = 0
+            o.GATED_BN_HITS[0] = 0
             net.zero_grad(set_to_none=True)
             y = net(x)
             y = y[0] if isinstance(y, (tuple, list)) else y
@@ -464,6 +465,8 @@ def test_gated_skip_gradient_equals_the_materialised_one():
             torch.cuda.synchronize()
             grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
             assert conv.GATED_SKIP_HITS[0] == (12 if gated else 0)
+            # ... and the four blocks WITH a downsample branch hand the unmasked gradient + mask to that branch's BatchNorm
+            assert o.GATED_BN_HITS[0] == (4 if gated else 0)
         assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
         for k in grads[0]:
             assert torch.equal(grads[0][k], grads[1][k]), k

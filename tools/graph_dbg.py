@@ -13,11 +13,17 @@ model.load_state_dict(synth.synth_state_dict(synth.spec_of(model.state_dict()), 
 model = model.to(dev).train()
 model.rng = deepv3.InjectedRandom((True, True, True), None, reinit=True)
 tr = Trainer(model)
-if len(sys.argv) > 1 and sys.argv[1] == "graph":
+# usage: tools/graph_dbg.py [graph | graph-old]   (graph-old: the round-2 capture -- on a stream other than the warm-up's)
+if len(sys.argv) > 1 and sys.argv[1].startswith("graph"):
     tr.enable_graph()
+    tr._debug_capture_on_fresh_stream = sys.argv[1] == "graph-old"
 x, y = synth.synth_batch(8, 512, 512, seed=1)
 x, y = x.to(dev), y.to(dev)
 for i in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     tr.step(x, y)
     torch.cuda.synchronize(); print(i, "%.2f ms" % (1e3 * (time.perf_counter() - t0)), flush=True)
+if tr.graph:
+    from mrfp_amd.harness import graph_topology
+    for key, entry in tr._graphs.items():
+        print("captured graph", key[0], graph_topology(entry[0]), flush=True)
