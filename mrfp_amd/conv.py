@@ -87,7 +87,7 @@ def _packable(pk, w, with_bias=False):
             and w.shape[2] * w.shape[3] <= 9)        # the brick kernel holds up to 3x3 taps; the 7x7 stem packs lazily
 
 
-def _batched_repack(todo, tag, biases=None):
+def _batched_repack(todo, tag, biases=None, launch=True):
     """ONE mrfp_pack_weights_batched launch per dtype for the (key, pack, weight) triples in `todo`; the job table is cached
     per (tag, dtype) and rebuilt only when the set of packs changes."""
     import numpy as np
@@ -108,9 +108,17 @@ def _batched_repack(todo, tag, biases=None):
                 bc = 64 if R * S == 1 else 8                                           # input channels per brick (conv.hip)
                 prefix[i + 1] = prefix[i] + ((Nphys + 63) // 64) * ((Cphys + bc - 1) // bc)
             dev = items[0][2].device
-            st = {"sig": sig, "jobs": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
-                  "prefix": torch.from_numpy(prefix).to(dev), "total": int(prefix[-1]), "n": len(items)}
+            # (pinned staging + asynchronous copies: legal while a hipGraph is being captured too -- the first capture pass of
+            #  Trainer.enable_graph() is the first time the HRFP packs exist when the re-initialisation runs; the host copies stay
+            #  alive in the table entry for the graph's memcpy nodes)
+            hj, hp = torch.from_numpy(rec.view(np.uint8).copy()), torch.from_numpy(prefix)
+            if dev.type == "cuda":
+                hj, hp = hj.pin_memory(), hp.pin_memory()
+            st = {"sig": sig, "host": (hj, hp), "jobs": hj.to(dev, non_blocking=True),
+                  "prefix": hp.to(dev, non_blocking=True), "total": int(prefix[-1]), "n": len(items)}
             _BATCH[(tag, dtype)] = st
+        if not launch:
+            continue
         call("mrfp_pack_weights_batched", ptr(st["jobs"]), ptr(st["prefix"]), st["n"], st["total"], _lib._DT[dtype], stream())
         capturing = torch.cuda.is_current_stream_capturing()
         for key, pk, w in items:
@@ -142,6 +150,33 @@ def repack_weights(weights, tag="list", biases=None):
     re-initialisation: reference deepv3.py:290-299 re-draws them at the start of a forward; 28 pack launches per step
     otherwise).  `biases`: the bias Parameter of each weight (or None) -- a pack with a bias gets its fp32 copy refreshed here too.
     Weights without a cached pack yet are left to the lazy path."""
+    _REPACK_LISTS[tag] = ([weakref.ref(w) for w in weights], [weakref.ref(b) if b is not None else None for b in biases]
+                          if biases is not None else None)
+    todo, bmap = _repack_selection(weights, biases)
+    if todo:
+        _batched_repack(todo, tag, bmap)
+
+
+_REPACK_LISTS = {}       # tag -> the (weights, biases) of the last repack_weights() call
+
+
+def prebuild_repack_tables():
+    """Builds (without launching) the job tables of every repack_weights() list seen so far, for the packs that exist NOW: called
+    by harness.Trainer between the eager warm-up pass of a hipGraph capture and the capture itself -- in the very first step the
+    packs of the HRFP convolutions come into being AFTER the re-initialisation ran, so the capture pass would be the first to
+    need the table, and a host -> device copy cannot be captured."""
+    for tag, (wrefs, brefs) in list(_REPACK_LISTS.items()):
+        weights = [r() for r in wrefs]
+        if any(w is None for w in weights):          # the model is gone
+            del _REPACK_LISTS[tag]
+            continue
+        biases = [r() if r is not None else None for r in brefs] if brefs is not None else None
+        todo, bmap = _repack_selection(weights, biases)
+        if todo:
+            _batched_repack(todo, tag, bmap, launch=False)
+
+
+def _repack_selection(weights, biases):
     todo = []
     bmap = {id(w): b for w, b in zip(weights, biases)} if biases is not None else {}
     for w in weights:
@@ -150,8 +185,7 @@ def repack_weights(weights, tag="list", biases=None):
             if pk.wf is not None and _packable(pk, w, with_bias=has_b) and (pk.bias is None) == (not has_b) \
                     and key[4] == (bmap[id(w)].data_ptr() if has_b else 0):
                 todo.append((key, pk, w))
-    if todo:
-        _batched_repack(todo, tag, bmap)
+    return todo, bmap
 
 
 def _out_size(H, R, stride, pad, dil):

@@ -419,7 +419,13 @@ template <typename T, int WM, int WN, bool DMA, bool DENSE = false, int TMB = 2>
 static int launch_wgrad_v(const WgP& p, int splits, hipStream_t st, const WgGroup* grp) {
     constexpr int BNN = 32 * TMB * WM;
     constexpr int PY = BNN * (int)sizeof(T) + (DMA ? 0 : 64), PX = 64 * WN * (int)sizeof(T) + (DMA ? 0 : 64);
-    const int lds = WgTile<T>::BKP * (PY + PX);
+    // MRFP_WGRAD_LDS=<bytes> (experiments: tools/overlap_micro.py): ask for at least that much LDS per workgroup, i.e. cap the
+    // workgroups per CU below what the registers allow (81920: one per CU) -- how much of a concurrent HBM-bound kernel's time
+    // a weight-gradient launch can hide in when it leaves register file and wave slots free
+    static int lds_min = -1;
+    if (lds_min < 0) { const char* e = getenv("MRFP_WGRAD_LDS"); lds_min = e ? atoi(e) : 0; }
+    const int lds_need = WgTile<T>::BKP * (PY + PX);
+    const int lds = lds_need > lds_min ? lds_need : lds_min;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, WM, WN, DMA, DENSE, TMB>),

@@ -378,6 +378,7 @@ class Trainer:
                 from . import conv
                 conv.join_wgrad_stream()
                 self.opt.step(1.0 / self.loss_scale)
+                conv.prebuild_repack_tables()            # (job tables of the batched re-packs: no host -> device copy inside the capture)
                 # capture on the warm-up's stream, with the warm-up's autograd graph gone (.detach() above): a gradient
                 # accumulator that remembers another stream makes autograd fork / join the capture once per parameter, and
                 # the replay of such a graph pays a cross-queue barrier per fork (35 vs 15 ms on ResNet-50 8x512^2)

@@ -184,6 +184,28 @@ def test_graph_mode_matches_eager():
         assert topo["nodes"] > 500 and topo["forks"] == 0 and topo["joins"] == 0 and topo["roots"] == 1, topo
 
 
+def test_graph_mode_with_hrfp_redraw_inside_the_graph():
+    """The bench's configuration of graph mode: the HRFP weights are re-drawn at the start of every forward (reference
+    deepv3.py:290-306) INSIDE the captured graph (graph-safe Philox), followed by the batched re-pack of their convolution packs --
+    whose job table is built the first time the packs exist when the re-initialisation runs, i.e. during the capture pass (pinned
+    staging + asynchronous copy: a legal memcpy node).  Replays must re-draw (the weights change from step to step) and train."""
+    from mrfp_amd.deepv3 import InjectedRandom
+    from mrfp_amd.harness import Trainer
+    x, y = synth.synth_batch(2, 128, 128, seed=3)
+    x, y = x.to(DEV), y.to(DEV)
+    model, _ = _model()
+    model.train()
+    tr = Trainer(model, lr=1e-3).enable_graph()
+    model.rng = InjectedRandom((True, True, True), None, reinit=True)
+    losses, ws = [], []
+    for _ in range(4):
+        losses.append(float(tr.step(x, y)))
+        ws.append(model.OClayer1.weight.detach().clone())
+    assert all(np.isfinite(losses)), losses
+    assert len(tr._graphs) == 1
+    assert not torch.equal(ws[1], ws[2]) and not torch.equal(ws[2], ws[3])          # replays re-draw
+
+
 def test_graph_mode_with_one_hardware_queue_in_subprocess():
     """GPU_MAX_HW_QUEUES=1 (read by the HIP runtime at start-up: a child process): capture + three replays of the ResNet-50 step
     must run and reproduce the eager losses bit for bit -- with the round-2 capture this configuration crashed inside
