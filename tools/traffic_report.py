@@ -16,7 +16,7 @@ import os
 import subprocess
 import sys
 
-TAG = os.environ.get("MRFP_ROUND", "r03")
+TAG = os.environ.get("MRFP_ROUND", "r04")
 FAMILIES = (("conv", ("conv_igemm_kernel", "conv_wgrad_kernel", "wgrad_reduce_kernel", "conv1x1_bstat_kernel", "conv_pw", "compact_stats_kernel")),
             ("normalisation", ("stats_kernel", "affine_fwd_kernel", "affine_bwd_kernel", "finalize_kernel", "copy_channels_kernel")),
             )

@@ -1,5 +1,6 @@
 """Weight-gradient launches of the bench step, single and grouped, under the current environment switches (MRFP_WGRAD_BIG=0/1/2,
-MRFP_WGRAD_WGS, ...): microseconds per problem and TFLOP/s.   python tools/wgrad_micro.py [reps]"""
+MRFP_WGRAD_WGS, ...): microseconds per problem and TFLOP/s.   python tools/wgrad_micro.py [reps [shape index [single|grouped]]]
+(one shape, one form: the program behind `rocprofv3 --pmc` in tools/run_pmc_wgrad.sh)"""
 import ctypes
 import os
 import sys
@@ -18,6 +19,9 @@ SHAPES = [(16, 48, 48, 256, 1024, 1, 1, 0, 1, 23), (16, 48, 48, 1024, 256, 1, 1,
           (16, 48, 48, 1024, 2048, 1, 1, 0, 1, 1), (16, 96, 96, 128, 512, 1, 1, 0, 1, 4), (16, 96, 96, 512, 128, 1, 1, 0, 1, 3),
           (16, 192, 192, 64, 256, 1, 1, 0, 1, 3), (16, 96, 96, 512, 256, 1, 1, 0, 1, 1), (16, 48, 48, 1280, 256, 1, 1, 0, 1, 1)]
 L = _lib.lib()
+if len(sys.argv) > 2:
+    SHAPES = [SHAPES[int(sys.argv[2])]]
+FORMS = sys.argv[3:4] or ["singles", "grouped"]
 for (B, H, W, C, N, k, st, pad, dil, G) in SHAPES:
     Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
     M, Q = B * Ho * Wo, k * k * C
@@ -38,6 +42,9 @@ for (B, H, W, C, N, k, st, pad, dil, G) in SHAPES:
                  stream())
     out = []
     for fn in (singles, grouped):
+        if not any(fn.__name__.startswith(f[:6]) for f in FORMS):
+            out.append(float("nan"))
+            continue
         fn()
         torch.cuda.synchronize()
         best = 1e30
