@@ -72,6 +72,7 @@ struct ConvP {
     int N, ldy;
     int R, S, Ho, Wo;
     int stride, pad_h, pad_w, dil, sstride;
+    int classed;        // STRIDED launches (sstride == 2): rows are enumerated parity class by parity class (conv_igemm.hip)
     int M, cpr, kchunks;
     unsigned xbytes, wbytes;   // sizes of x and of the weight pack (buffer descriptors)
 };

@@ -51,6 +51,33 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
 
+    // CLASSED (dgrad of a stride-2 convolution, host: conv_fwd_impl): an output pixel (oh, ow) only has the taps r = (pad_h + oh) mod 2
+    // (+2, ...), s likewise -- a quarter of them on average, and which ones depends on the pixel's PARITY CLASS (oh & 1, ow & 1).  With
+    // rows enumerated pixel by pixel every tile mixes the four classes and walks all R*S taps, zero-filling three quarters of its
+    // fills and multiplies.  Here the row index is class-major -- m = class * Mc + ((b * Ho/2 + i) * Wo/2 + j), pixel (2i + ph, 2j + pw),
+    // Mc a multiple of the tile height -- so a tile's rows share their taps: the K loop walks only those (none at all for three of
+    // the four classes of a 1x1 stride-2 convolution: those tiles just store zeros + addend), and the epilogue scatters the rows back.
+    // p.classed == 2 (pointwise stride-2 convolution: only the even-even pixels have a tap at all): the rows are the even-even pixels
+    // alone (M = Mc), and the epilogue stores each row's 2 x 2 output block -- its value and three zeros (+ addend) -- so that the
+    // output is written in two-pixel runs and no tile exists only to store zeros.
+    const bool classed = STRIDED && p.classed != 0;
+    const bool quad = STRIDED && p.classed == 2;
+    const int cHc = p.Ho >> 1, cWc = p.Wo >> 1, cMc = p.B * cHc * cWc;
+    const int cls = (classed && !quad) ? m0 / cMc : 0, cph = cls >> 1, cpw = cls & 1;
+    auto pixel_of = [&](int m, int& b, int& oh, int& ow) {
+        if (classed) {
+            const int mm = m - cls * cMc;
+            b = mm / (cHc * cWc);
+            const int rem = mm - b * (cHc * cWc), i2 = rem / cWc;
+            oh = 2 * i2 + cph;
+            ow = 2 * (rem - i2 * cWc) + cpw;
+        } else {
+            b = m / (p.Ho * p.Wo);
+            const int rem = m - b * (p.Ho * p.Wo);
+            oh = rem / p.Wo;
+            ow = rem - oh * p.Wo;
+        }
+    };
     // fixed per-thread gather state for its SA rows of the A tile
     int a_ih0[SA], a_iw0[SA];
     unsigned a_base[SA];   // !STRIDED: byte offset of pixel (b, ih0, iw0) (mod 2^32); STRIDED: offset of image b
@@ -58,8 +85,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
     for (int i = 0; i < SA; ++i) {
         const int m = m0 + rbase + i * RSTEP;
         if (m < p.M) {
-            const int b = m / (p.Ho * p.Wo), rem = m - b * (p.Ho * p.Wo);
-            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            int b, oh, ow;
+            pixel_of(m, b, oh, ow);
             a_ih0[i] = oh * p.stride - p.pad_h;
             a_iw0[i] = ow * p.stride - p.pad_w;
             a_base[i] = STRIDED ? (unsigned)(b * p.H * p.W) * (unsigned)pixbytes
@@ -78,7 +105,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
     }
 
     // tap tracking: scalar (r, s, tile-in-tap) when ALIGNED, per-thread (r, s, chunk-in-tap) otherwise
-    int tr = 0, ts = 0, tc = 0;
+    // (CLASSED: the first tap of this tile's class along each axis, every second one after it)
+    const int tr0 = classed ? ((p.pad_h + cph) & 1) : 0, ts0 = classed ? ((p.pad_w + cpw) & 1) : 0, tstep = classed ? 2 : 1;
+    int tr = tr0, ts = ts0, tc = 0;
     if (!ALIGNED) {
         const int rs = chunk / p.cpr;
         tc = chunk - rs * p.cpr;
@@ -122,9 +151,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
         // by the XCD's L2 instead of the fabric (the working set of a tap-outer order, 3 image rows x all channels x
         // 32 workgroups, does not fit the 4 MiB L2; measured: the 256x256 kernel was fill-bound at 6.3 TB/s).
         if (ALIGNED) {
-            if (++ts == p.S) {
-                ts = 0;
-                if (++tr == p.R) { tr = 0; ++tc; }
+            ts += tstep;
+            if (ts >= p.S) {
+                ts = ts0;
+                tr += tstep;
+                if (tr >= p.R) { tr = tr0; ++tc; }
             }
         } else {
             tc += 8;
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
 
-    const int nkt = (p.kchunks + 7) >> 3;
+    const int nkt = classed ? ((p.R - tr0 + 1) >> 1) * ((p.S - ts0 + 1) >> 1) * (p.cpr >> 3) : (p.kchunks + 7) >> 3;
     const int lr = lane & 31, lh = lane >> 5;
     const int l15 = lane & 15, lq = lane >> 4;
     auto compute = [&](int kk0 = 0, int kk1 = 2) {
@@ -303,7 +334,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
             // of the tile's occupancy allows it (MRFP_EARLY_FULL, bit 0: 96x128 tile, bit 1: 128x128 tile)
             constexpr int HOLD = ((TM * TN == 3 && (MRFP_EARLY_FULL & 1)) || (TM * TN == 4 && WM == 2 && WN == 2 && (MRFP_EARLY_FULL & 2))) ? 2 : 1;
             uint4 fa[HOLD][2 * TM], fb[HOLD][2 * TN];
-            load_tile(0);
+            if (nkt > 0) load_tile(0);
             for (int kt = 0; kt < nkt; ++kt) {
                 // EXPLICIT vmcnt(0): across the loop's back edge the compiler puts its own wait for the builtin's transfers AFTER
                 // the barrier (`s_waitcnt vmcnt(5); s_barrier; s_waitcnt vmcnt(0); ds_read` in the ISA) -- a wave would pass the
@@ -405,9 +436,22 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int row = (WIDE ? wn * (32 / WN) : 0) + k * RPI + lane / CPRW, ch = lane % CPRW;
-            const int m = mb + row, n = (WIDE ? n0 : nb) + ch * EPC;
-            if (m < p.M && n < p.N) {
+            const int mlog = mb + row, n = (WIDE ? n0 : nb) + ch * EPC;
+            if (mlog < p.M && n < p.N) {
+                int m = mlog;
+                if (classed) {       // back from the class-major row index to the pixel's row of the output
+                    int b, oh, ow;
+                    pixel_of(mlog, b, oh, ow);
+                    m = (b * p.Ho + oh) * p.Wo + ow;
+                }
                 uint4 v = *reinterpret_cast<const uint4*>(epr + row * EPITCH + ch * 16);
+                const int mquad = m;
+#pragma unroll 1
+                for (int qd = 0; qd < (quad ? 4 : 1); ++qd) {
+                if (qd > 0) {          // the three tap-less pixels of the 2 x 2 block: zeros (+ addend)
+                    m = mquad + (qd >> 1) * p.Wo + (qd & 1);
+                    v = make_uint4(0u, 0u, 0u, 0u);
+                }
                 T* dst = y + (size_t)m * p.ldy + n;
                 const bool full = n + EPC <= p.N;
                 // (everything below indexes the chunk with compile-time constants only: a run-time index would
@@ -434,6 +478,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
                     for (int u = 0; u < EPC; ++u)
                         if (n + u < p.N) dst[u] = chunk_get<T>(v, u);
                 }
+                }       // qd
             }
         }
         if constexpr (WIDE) __syncthreads();
@@ -683,6 +728,16 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
     p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    {   // dgrad of a stride-2 convolution: parity-class-major rows (see the kernel) where the geometry allows it -- even output size,
+        // whole 64-channel K tiles, classes of whole (<= 256-row) tiles, one launch.  MRFP_DGRAD_CLASSED=0: the per-pixel form (A/B runs)
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("MRFP_DGRAD_CLASSED"); on = e ? atoi(e) : 1; }
+        p.classed = on && sstride == 2 && stride == 1 && dil == 1 && (Ho & 1) == 0 && (Wo & 1) == 0 && (p.cpr & 7) == 0 &&
+                    ((B * (Ho / 2) * (Wo / 2)) % 256) == 0 && !colstats;
+        // pointwise: rows = the even-even pixels only, the epilogue stores 2 x 2 blocks (measured: three classes of store-only tiles
+        // made the class-major form 20 % SLOWER than the per-pixel one on the 1x1 stride-2 downsample dgrads)
+        if (p.classed && R == 1 && S == 1 && pad_h == 0 && pad_w == 0) p.classed = 2;
+    }
     const int64_t img = H * W * C * esz, wb = N * (int64_t)p.kchunks * 16;      // bytes of one input image, of the pack
     MRFP_CHECK(img < (int64_t)kOOB && wb < (int64_t)kOOB,
                "conv_fwd: one input image / the weight pack exceeds the 3.75 GB buffer-descriptor range");
@@ -694,6 +749,7 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
     const int64_t bmax = (int64_t)(kOOB - 1) / img;          // images per launch
     const bool chunked = B > bmax;
     MRFP_CHECK(!chunked || !colstats, "conv_fwd: fused statistics are not available for inputs above 3.75 GB (see mrfp_conv_single_launch)");
+    if (chunked) p.classed = 0;          // (batch ranges: the class size would change per range)
     int dbg_drop = 0;
     {   // timing-only diagnostics: zero-record descriptors drop that operand's traffic, instruction stream unchanged
         static int dbg = -1;
@@ -705,7 +761,7 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
         const int64_t bc = B - b0 < bmax ? B - b0 : bmax;
         const int64_t m0 = b0 * Ho * Wo;
         p.B = (int)bc;
-        p.M = (int)(bc * Ho * Wo);
+        p.M = p.classed == 2 ? (int)(bc * (Ho / 2) * (Wo / 2)) : (int)(bc * Ho * Wo);
         p.x = (const char*)x + b0 * img;
         p.y = (char*)y + m0 * ldy * esz;
         p.addend = addend ? (const char*)addend + m0 * ldy * esz : nullptr;
@@ -770,6 +826,7 @@ int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
     p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    p.classed = 0;
     p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
     return stats_row_blocks(p, esz);
 }

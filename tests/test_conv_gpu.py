@@ -38,6 +38,11 @@ CASES = [
     (1, 256, 7, 9, 136, 1, 1, 0, 1, False),
     (2, 128, 96, 96, 200, 1, 1, 0, 1, False),
     (4, 256, 48, 48, 1024, 1, 1, 0, 1, False),   # several tiles per workgroup: the ring wraps
+    # dgrad of a stride-2 convolution with parity-class-major rows (even sizes, classes of whole tiles): 3x3 (1, 2, 2, 4 taps per
+    # class), 1x1 (one class with a tap, three that only store zeros), the 256x64 tile (N <= 64 in dgrad form)
+    (4, 128, 32, 32, 128, 3, 2, 1, 1, False),
+    (4, 256, 32, 32, 512, 1, 2, 0, 1, False),
+    (4, 64, 64, 48, 128, 3, 2, 1, 1, False),
 ]
 
 
@@ -306,6 +311,47 @@ def test_grouped_wgrad_equals_the_single_launches(dtype, case):
         if i in (0, n - 1):
             ref = torch.nn.grad.conv2d_weight(xs[i][:, :C].float().cpu(), (N, C, k, k), dys[i][:, :N].float().cpu(), stride, pad, dil)
             assert relerr(a[i], ref) < (2e-5 if dtype == torch.float32 else 1e-4)
+
+
+def test_strided_dgrad_class_major_rows_equal_the_per_pixel_form():
+    """dgrad of a stride-2 convolution (reference Resnet.py:202-216 conv2 of the first block of a stage, :579-585 its downsample
+    branch): with the output rows enumerated parity class by parity class a tile walks only the taps its class has.  The same
+    nonzero products in the same order as the per-pixel form (MRFP_DGRAD_CLASSED=0, child process; it adds exact zeros for the taps
+    that do not exist): bit-identical dx, also with a skip-gradient addend in the epilogue, and equal to torch's gradient."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch, torch.nn.functional as F\n"
+        "from mrfp_amd import conv, ops\n"
+        "out = {}\n"
+        "for (B,C,H,W,N,k,pad) in [(4,128,32,32,128,3,1),(4,256,32,32,512,1,0),(4,64,64,48,128,3,1),(16,256,96,96,256,3,1)]:\n"
+        "    g = torch.Generator(device='cuda:0').manual_seed(5)\n"
+        "    x = torch.randn(B,C,H,W,device='cuda:0',generator=g).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)\n"
+        "    w = (torch.randn(N,C,k,k,device='cuda:0',generator=g)*0.05).requires_grad_(True)\n"
+        "    y, skip = conv.conv2d(x, w, None, 2, pad, 1, want_skip=True)\n"
+        "    gy = torch.randn(y.shape,device='cuda:0',generator=g).bfloat16().contiguous(memory_format=torch.channels_last)\n"
+        "    z = ops.add(skip, skip)\n"                       # a second consumer of the block input: its gradient is the dgrad's addend
+        "    gz = torch.randn(z.shape,device='cuda:0',generator=g).bfloat16().contiguous(memory_format=torch.channels_last)\n"
+        "    torch.autograd.backward([y, z], [gy, gz])\n"
+        "    ref = torch.nn.grad.conv2d_input(x.shape, w.detach().bfloat16().float().cpu(), gy.float().cpu(), 2, pad, 1) + 2 * gz.float().cpu()\n"
+        "    err = ((x.grad.float().cpu() - ref).abs().max() / ref.abs().max()).item()\n"
+        "    assert err < 1.5e-2, (C, N, k, err)\n"
+        "    out[(B,C,H,W,N,k)] = x.grad.cpu()\n"
+        "torch.save(out, sys.argv[1])\nprint('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for tag, extra in (("classed", {}), ("pixel", {"MRFP_DGRAD_CLASSED": "0"})):
+        f = os.path.join("/tmp", "mrfp_dgrad_%s_%d.pt" % (tag, os.getpid()))
+        env = dict(os.environ, PYTHONPATH=root, **extra)
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
+        files.append(f)
+    a, b = torch.load(files[0]), torch.load(files[1])
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for f in files:
+        os.remove(f)
 
 
 def test_wgrad_256x128_tile_in_subprocess():
