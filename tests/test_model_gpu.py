@@ -259,3 +259,50 @@ def test_full_size_properties():
         assert abs(fd - an) <= 0.02 * abs(an) + 1e-6, (fd, an)
     finally:
         cfg.MODEL.ACT_DTYPE = torch.float32
+
+
+def test_hrfp_reinitialisation_arena_matches_the_reference_initialiser():
+    """reference deepv3.py:291-306 + mynn.py:57-74: at the start of a forward with p < 0.5 the eight HRFP convolutions get
+    kaiming_normal_ weights and zero biases, their BatchNorms N(0, 0.5) weights and zero biases.  On the GPU the 32 tensors are views of
+    one flat arena and the re-draw is two kernels (normal_, multiply by the per-element standard deviation): same distribution per
+    tensor, parameters keep their names / shapes (state_dict ABI), a later load_state_dict still reaches them, and the forward uses
+    the re-drawn values (the convolution packs are rebuilt)."""
+    from mrfp_amd.deepv3 import InjectedRandom, ReferenceRandom
+    model, sd = build_model("hip", dtype=torch.bfloat16)
+    try:
+        model.train()
+        torch.manual_seed(0)
+        keys_before = list(model.state_dict().keys())
+        ReferenceRandom().reinit_hrfp(model)
+        assert getattr(model, "_hrfp_arena_state", None) is not None
+        for conv, bn in model.hrfp_layers():
+            fan_in = conv.weight.shape[1] * 9
+            w = conv.weight.detach().float()
+            assert abs(w.std().item() / (2.0 / fan_in) ** 0.5 - 1.0) < 0.05 and abs(w.mean().item()) < 3 * (2.0 / fan_in) ** 0.5 / w.numel() ** 0.5 + 1e-4
+            assert torch.count_nonzero(conv.bias).item() == 0 and torch.count_nonzero(bn.bias).item() == 0
+            assert abs(bn.weight.detach().std().item() / 0.5 - 1.0) < 0.35          # 64-256 samples
+        w1 = model.OClayer1.weight.detach().clone()
+        ReferenceRandom().reinit_hrfp(model)
+        assert not torch.equal(w1, model.OClayer1.weight.detach())
+        assert list(model.state_dict().keys()) == keys_before
+        # the forward sees the re-drawn weights: two forwards with different draws differ, two with the same weights agree
+        x, y = synth.synth_batch(2, 128, 128, seed=3)
+        x, y = x.to(DEV), y.to(DEV)
+        noise = {k: v.to(DEV) for k, v in synth.synth_noise(2, seed=4).items()}
+        model.rng = InjectedRandom((True, True, True), noise)          # (no re-draw inside forward)
+        la = float(model(x, y, training=True))
+        lb = float(model(x, y, training=True))
+        ReferenceRandom().reinit_hrfp(model)
+        lc = float(model(x, y, training=True))
+        assert la == lb and la != lc
+        # load_state_dict writes through the views
+        model.load_state_dict(sd)
+        assert torch.equal(model.OClayer1.weight.detach().cpu(), sd["OClayer1.weight"])
+        ld = float(model(x, y, training=True))
+        ref, _ = build_model("hip", dtype=torch.bfloat16)
+        ref.train()
+        ref.rng = InjectedRandom((True, True, True), noise)
+        assert ld == float(ref(x, y, training=True))
+    finally:
+        from mrfp_amd.config import cfg
+        cfg.MODEL.ACT_DTYPE = torch.float32
