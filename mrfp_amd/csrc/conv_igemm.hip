@@ -787,7 +787,7 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
 int mrfp_debug_clock_stamps(int family, uint64_t* out, int64_t n) {
     MRFP_CHECK(MRFP_CLOCK_STAMP != 0, "clock stamps: not a diagnostic build (-DMRFP_CLOCK_STAMP=1)");
     MRFP_CHECK(out && n > 0 && n <= kStampSlots && family >= 0 && family <= 2, "clock stamps: bad arguments");
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     const int rc = family == 0 ? stamps_igemm((unsigned long long*)out, (int)n)
                    : family == 1 ? stamps_pw((unsigned long long*)out, (int)n) : stamps_wgrad((unsigned long long*)out, (int)n);
     MRFP_CHECK(rc == 0, "clock stamps: read-back failed");
