@@ -124,6 +124,12 @@ int mrfp_affine_fwd(const void* x, const void* res, void* y, int dtype,
                     const int32_t* tabH, const int32_t* tabW,
                     const float* A, const float* S, int coef_per_image, int relu, void* stream);
 
+/* mrfp_affine_fwd (identity geometry) that also writes the per-workgroup partial sums of its STORED output, float ws[B][nslab][2][C]
+ * with nslab = mrfp_stats_nslab(B, H) -- bit for bit the rows mrfp_stats_fwd(y) would produce -- for a per-image normalisation of y that
+ * follows at once: the InstanceNorm behind a residual tail (reference Resnet.py:218-225) or NP+ behind an InstanceNorm
+ * (deepv3.py:333-335): feed ws to mrfp_in_finalize / mrfp_np_finalize and skip their statistics pass. */
+int mrfp_affine_fwd_stats(const void* x, const void* res, void* y, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
+                          const float* A, const float* S, int coef_per_image, int relu, float* ws, void* stream);
 int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int dtype,
                     int64_t B, int64_t Ho, int64_t Wo, int64_t C, int64_t Hs, int64_t Ws,
                     const int32_t* invH, const int32_t* invW,
@@ -239,6 +245,11 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
  * nslab = nblk, count = B*Ho*Wo). */
 int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho,
                                int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride);
+/* rows of the [M][N] output one of those row blocks covers (block r = rows [r * rb, (r + 1) * rb)): when rb divides Ho*Wo no block
+ * straddles an image and the blocks of image b are the per-image partial sums nn.InstanceNorm2d needs (reference Resnet.py:176-178,
+ * 534-536: InstanceNorm after the stem convolutions) -- feed them to mrfp_in_finalize with nslab = Ho*Wo / rb. */
+int64_t mrfp_conv_stats_block_rows(int dtype, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho,
+                                   int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride);
 /* takes the geometry arguments of the mrfp_conv_fwd call it describes: the kernel the launch runs on (tile shape, the pointwise
  * kernels, the row-reuse 3x3 kernels) -- and with it the number of row blocks -- depends on all of them. */
 /* The K-loop gathers through 32-bit buffer-descriptor offsets, so one launch reads at most 3.75 GB of input; a larger

@@ -403,7 +403,10 @@ class _Conv2d(torch.autograd.Function):
              Ho, Wo, stride, pad_h, pad_w, dil, 1, None, ptr(stats), stream())
         if stats is not None:      # the rows the BatchNorm finalize should read (compacted for large launches)
             first, cnt = int(L.mrfp_conv_stats_final_first(nblk)), int(L.mrfp_conv_stats_final_count(nblk))
-            _LAST_STATS[0] = (stats[first * 2 * Nphys:(first + cnt) * 2 * Nphys], cnt, B * Ho * Wo)
+            # (rows to hand to a BatchNorm finalize, their count, the element count; + the RAW per-row-block rows and their count: an
+            #  InstanceNorm consumer needs them per image -- ops._InstanceNormAct)
+            rb = int(L.mrfp_conv_stats_block_rows(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1))
+            _LAST_STATS[0] = (stats[first * 2 * Nphys:(first + cnt) * 2 * Nphys], cnt, B * Ho * Wo, stats, nblk, rb)
         else:
             _LAST_STATS[0] = None
         ctx.save_for_backward(x, weight, bias)

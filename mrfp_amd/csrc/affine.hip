@@ -87,6 +87,94 @@ __global__ __launch_bounds__(kThreads) void affine_fwd_kernel(const T* __restric
     }
 }
 
+// The same apply pass (identity geometry) that ALSO emits the per-workgroup partial sums of its STORED output -- exactly the rows
+// `stats_kernel<T, VEC, 0, false>` would write for y (same grid, same lines per workgroup, same per-thread accumulation order, same
+// LDS combination: bit-identical partials) -- for a consumer that normalises y per image next: the InstanceNorm behind a residual
+// tail (reference Resnet.py:218-225, the `iw` taps), NP+ behind an InstanceNorm (deepv3.py:333-335).  One pass over y disappears.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void affine_fwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                                    T* __restrict__ y, RowGeom g, int ly,
+                                                                    const float* __restrict__ A, const float* __restrict__ S,
+                                                                    int coef_per_image, int relu, float* __restrict__ ws) {
+    __shared__ float sm[kThreads * 2 * VEC];
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(g.C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    const bool active = trow < L.rowthreads;
+    const size_t cbase = (size_t)(coef_per_image ? b : 0) * g.C;
+    float* out = ws + (size_t)blockIdx.x * 2 * g.C;
+    for (int cv0 = 0; cv0 < L.lpr; cv0 += kThreads) {
+        const int cv = cv0 + tcol;
+        const bool on = active && cv < L.lpr;
+        float a[VEC], s[VEC], su[VEC], sq[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { a[i] = 1.f; s[i] = 0.f; su[i] = 0.f; sq[i] = 0.f; }
+        if (on) {
+            if (A) load_coef<VEC>(A + cbase + (size_t)cv * VEC, a);
+            if (S) load_coef<VEC>(S + cbase + (size_t)cv * VEC, s);
+            for (int oh = j; oh < g.Ho; oh += ly) {
+                const size_t dl = ((size_t)b * g.Ho + oh) * g.Wo * g.C + (size_t)cv * VEC;
+                for (int ow0 = trow; ow0 < g.Wo; ow0 += 4 * L.rowthreads) {
+                    VecT<T, VEC> xr[4], rr[4];
+                    int owc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) owc[u] = min(ow0 + u * L.rowthreads, g.Wo - 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        xr[u] = load_raw_nt<T, VEC>(x + dl + (size_t)owc[u] * g.C);
+                        if (res) rr[u] = load_raw_nt<T, VEC>(res + dl + (size_t)owc[u] * g.C);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ow = ow0 + u * L.rowthreads;
+                        const bool inside = ow < g.Wo;
+                        float v[VEC];
+                        cvt_f<T, VEC>(xr[u], v);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[i] = v[i] * a[i] + s[i];
+                        if (res) {
+                            float r[VEC];
+                            cvt_f<T, VEC>(rr[u], r);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) v[i] += r[i];
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                        }
+                        if (inside) store_f<T, VEC>(y + dl + (size_t)ow * g.C, v);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {        // what the statistics pass would read back: the rounded stored value
+                            const float vr = inside ? to_f(from_f<T>(v[i])) : 0.f;
+                            su[i] += vr;
+                            sq[i] += vr * vr;
+                        }
+                    }
+                }
+            }
+        }
+        // combine the row-threads of each channel vector through LDS (as stats_kernel does)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sm[(t * 2 + 0) * VEC + i] = su[i];
+            sm[(t * 2 + 1) * VEC + i] = sq[i];
+        }
+        __syncthreads();
+        const int nout = L.colthreads * 2 * VEC;
+        for (int o = t; o < nout; o += kThreads) {
+            const int oc = o / (2 * VEC), rest = o % (2 * VEC);
+            if (cv0 + oc < L.lpr) {
+                float acc = 0.f;
+                for (int r = 0; r < L.rowthreads; ++r) acc += sm[((r * L.colthreads + oc) * 2) * VEC + rest];
+                const int stat = rest / VEC, i = rest % VEC;
+                out[(size_t)stat * g.C + (size_t)(cv0 + oc) * VEC + i] = acc;
+            }
+        }
+    }
+}
+
 // Backward, walking SOURCE lines.  invH[2*ih], invH[2*ih+1] = half-open range of destination rows that
 // read source row ih (NULL = identity).  dres (destination geometry) is only supported with
 // identity maps (the residual branches of the network never sit behind a resize).
@@ -454,6 +542,31 @@ int mrfp_affine_fwd(const void* x, const void* res, void* y, int dtype, int64_t 
     if (dtype == MRFP_BF16) return launch_affine_fwd<bf16>(x, res, y, B, Ho, Wo, C, Hs, Ws, tabH, tabW, A, S, coef_per_image, relu, st);
     if (dtype == MRFP_F16) return launch_affine_fwd<f16>(x, res, y, B, Ho, Wo, C, Hs, Ws, tabH, tabW, A, S, coef_per_image, relu, st);
     MRFP_CHECK(false, "affine_fwd: unknown dtype %d", dtype);
+}
+
+int mrfp_affine_fwd_stats(const void* x, const void* res, void* y, int dtype, int64_t B, int64_t H, int64_t W, int64_t C,
+                          const float* A, const float* S, int coef_per_image, int relu, float* ws, void* stream) {
+    MRFP_CHECK(x && y && ws && B > 0 && H > 0 && W > 0 && C > 0, "affine_fwd_stats: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    RowGeom g{(int)B, (int)H, (int)W, (int)C, (int)H, (int)W, nullptr, nullptr};
+    const int ly = lines_per_image(B, H);
+    const bool al = aligned16(x) && aligned16(y) && (!res || aligned16(res)) && (!A || aligned16(A)) && (!S || aligned16(S));
+#define MRFP_AFS(TT)                                                                                                           \
+    do {                                                                                                                       \
+        if (pick_vec<TT>(C) > 1 && al)                                                                                         \
+            hipLaunchKernelGGL((affine_fwd_stats_kernel<TT, FullVec<TT>::value>), dim3((unsigned)(B * ly)), dim3(kThreads), 0, st, (const TT*)x,  \
+                               (const TT*)res, (TT*)y, g, ly, A, S, coef_per_image, relu, ws);                                   \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((affine_fwd_stats_kernel<TT, 1>), dim3((unsigned)(B * ly)), dim3(kThreads), 0, st, (const TT*)x,  \
+                               (const TT*)res, (TT*)y, g, ly, A, S, coef_per_image, relu, ws);                                   \
+    } while (0)
+    if (dtype == MRFP_F32) MRFP_AFS(float);
+    else if (dtype == MRFP_BF16) MRFP_AFS(bf16);
+    else if (dtype == MRFP_F16) MRFP_AFS(f16);
+    else MRFP_CHECK(false, "affine_fwd_stats: unknown dtype %d", dtype);
+#undef MRFP_AFS
+    MRFP_LAUNCH_CHECK();
+    return 0;
 }
 
 int mrfp_affine_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, int dtype, int64_t B,

@@ -292,6 +292,7 @@ __device__ __forceinline__ uint4 gate_chunk16(const uint4& v, unsigned bits) {
 // ---- pointwise (1x1, stride 1) short-K kernels, conv_pw.hip ----------------------------------------------------------------
 bool pw_applicable(const ConvP& p, int esz);          // does run_igemm hand this launch to conv_pw.hip?
 int64_t pw_stats_blocks(const ConvP& p);              // statistics row blocks such a launch writes
+int64_t pw_stats_block_rows(const ConvP& p);          // output rows one of them covers
 int pw_run(const ConvP& p, bool is_f16, hipStream_t st);
 
 }  // namespace mrfp

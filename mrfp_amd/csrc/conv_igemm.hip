@@ -684,6 +684,16 @@ static int64_t stats_row_blocks(const ConvP& p, int esz) {
     return (int64_t)((p.M + 127) / 128) * 2;                          // <2,2,2,2>: 128-row tile, 2 wave rows
 }
 
+// output rows one statistics row block covers (block r = rows [r * rb, (r + 1) * rb) of the [M][N] output)
+static int64_t stats_block_rows(const ConvP& p, int esz) {
+    if (pw_applicable(p, esz)) return pw_stats_block_rows(p);
+    if (rr_tile(p, esz)) return 96;
+    if (p.N > 64 && use_tile192(p, esz)) return 96;
+    if (p.N <= 64) return 64;
+    if (use_tile96(p, esz)) return 96;
+    return 64;
+}
+
 template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
@@ -829,6 +839,18 @@ int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64
     p.classed = 0;
     p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
     return stats_row_blocks(p, esz);
+}
+int64_t mrfp_conv_stats_block_rows(int dtype, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho,
+                                   int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride) {
+    ConvP p;
+    const int esz = dtype == MRFP_F32 ? 4 : 2;
+    p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)N;
+    p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
+    p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
+    p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
+    p.classed = 0;
+    p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
+    return stats_block_rows(p, esz);
 }
 /* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */
 int64_t mrfp_conv_stats_rows(int64_t nblk) { return nblk > kCompactAbove ? nblk + kStatGroups : nblk; }

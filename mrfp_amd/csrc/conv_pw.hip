@@ -357,6 +357,10 @@ static int run_bstat(const ConvP& p, hipStream_t st) {
 
 bool pw_applicable(const ConvP& p, int esz) { return use_bstat(p, esz); }
 int64_t pw_stats_blocks(const ConvP& p) { return (int64_t)bstat_chunks(p.M, p.N); }
+int64_t pw_stats_block_rows(const ConvP& p) {      // rows of one statistics row block (a workgroup's tile range)
+    const int tiles = (p.M + 63) / 64, chunks = bstat_chunks(p.M, p.N);
+    return (int64_t)((tiles + chunks - 1) / chunks) * 64;
+}
 int pw_run(const ConvP& p, bool is_f16, hipStream_t st) { return is_f16 ? run_bstat<f16>(p, st) : run_bstat<bf16>(p, st); }
 
 }  // namespace mrfp

@@ -23,7 +23,7 @@ from . import ops
 from .config import cfg
 from .conv import wgrad_boundary
 from .network import Resnet
-from .network.mynn import (HipBatchNorm2d, HipConv2d, Norm2d, Upsample, initialize_weights,
+from .network.mynn import (HipBatchNorm2d, HipConv2d, HipInstanceNorm2d, Norm2d, Upsample, initialize_weights,
                            initialize_weights_kaimingnormal_forOC)
 
 __all__ = ["_AtrousSpatialPyramidPoolingModule", "MRFPPlus", "simpleDeepV3Plus", "ReferenceRandom", "InjectedRandom"]
@@ -420,6 +420,9 @@ class MRFPPlus(_DeepLabBase):
                 self._tap("np1", t)
             if o1:
                 t = ops.add(OCout, t)
+        tap = getattr(self.layer1[-1], "instance_norm_layer", None) if hasattr(self, "layer1") else None
+        if isinstance(tap, HipInstanceNorm2d):
+            tap._emit_plane_stats = bool(npp) and fourier is None      # NP+ reads layer1's output next: its apply pass sums it
         t = self._low(t, w_arr)
         if fourier is not None:
             t = fourier.at("layer1", t)

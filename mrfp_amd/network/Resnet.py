@@ -75,7 +75,8 @@ class _Block(nn.Module):
     def _tail(self, last_bn, out, x, w_arr):
         residual = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))
         if self.iw >= 1:
-            out = last_bn.fused(out, res=residual)
+            # (iw 3 / 4: an InstanceNorm reads this output next -- the apply pass hands it the plane sums)
+            out = last_bn.fused(out, res=residual, emit_stats=self.iw in (3, 4) and isinstance(last_bn, mynn.HipBatchNorm2d))
             out = _norm_relu(self.instance_norm_layer, self.iw, out, w_arr)
         else:
             out = last_bn.fused(out, res=residual, relu=True)

@@ -32,7 +32,7 @@ class HipBatchNorm2d(nn.BatchNorm2d):
         self._nbt_pending = 0
         super()._load_from_state_dict(*args, **kwargs)
 
-    def fused(self, x, *, relu=False, res=None, plan=None):
+    def fused(self, x, *, relu=False, res=None, plan=None, emit_stats=False):
         training = self.training or (self.running_mean is None)
         if training and self.num_batches_tracked is not None:
             self._nbt_pending += 1
@@ -40,7 +40,7 @@ class HipBatchNorm2d(nn.BatchNorm2d):
                                   self.running_mean if self.track_running_stats else None,
                                   self.running_var if self.track_running_stats else None,
                                   training=training, momentum=self.momentum, eps=self.eps,
-                                  relu=relu, res=res, plan=plan)
+                                  relu=relu, res=res, plan=plan, emit_stats=emit_stats)
 
     def forward(self, x):
         return self.fused(x)
@@ -49,8 +49,10 @@ class HipBatchNorm2d(nn.BatchNorm2d):
 class HipInstanceNorm2d(nn.InstanceNorm2d):
     """nn.InstanceNorm2d (affine or not, no running stats) on the HIP kernels."""
 
+    _emit_plane_stats = False      # set by a caller that runs NP+ on this layer's output next (deepv3.MRFPPlus.forward)
+
     def fused(self, x, *, relu=False):
-        return ops.instance_norm_act(x, self.weight, self.bias, eps=self.eps, relu=relu)
+        return ops.instance_norm_act(x, self.weight, self.bias, eps=self.eps, relu=relu, emit_stats=self._emit_plane_stats)
 
     def forward(self, x):
         return self.fused(x)

@@ -306,3 +306,38 @@ def test_hrfp_reinitialisation_arena_matches_the_reference_initialiser():
     finally:
         from mrfp_amd.config import cfg
         cfg.MODEL.ACT_DTYPE = torch.float32
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_plane_statistics_from_the_producing_apply_pass_are_bit_identical(dtype):
+    """mrfp_affine_fwd_stats: the residual tails in front of the two InstanceNorm `iw` taps (reference Resnet.py:218-225) and the
+    InstanceNorm in front of the second NP+ (deepv3.py:333-335) also write the partial plane sums of their stored output -- the rows the
+    statistics pass over that output would produce, bit for bit -- and those three passes are skipped: loss and every gradient
+    identical with the switch off."""
+    from mrfp_amd import ops as o
+    from mrfp_amd.deepv3 import InjectedRandom
+    x, y = synth.synth_batch(2, 128, 128, seed=3)
+    x, y = x.to(DEV), y.to(DEV)
+    noise = {k: v.to(DEV) for k, v in synth.synth_noise(2, seed=4).items()}
+    out = []
+    try:
+        for on in (True, False):
+            o.PLANE_STATS[0] = on
+            o.PLANE_STATS_HITS[0] = 0
+            model, _ = build_model("hip", dtype=dtype)
+            model.train()
+            model.rng = InjectedRandom((True, True, True), noise)
+            loss = model(x, y, training=True)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                        o.PLANE_STATS_HITS[0]))
+    finally:
+        o.PLANE_STATS[0] = True
+        from mrfp_amd.config import cfg
+        cfg.MODEL.ACT_DTYPE = torch.float32
+    assert out[0][2] == 3 and out[1][2] == 0
+    assert out[0][0] == out[1][0]
+    assert out[0][1].keys() == out[1][1].keys()
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k

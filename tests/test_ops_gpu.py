@@ -556,3 +556,46 @@ def test_padded_decoder_concat_feeds_a_channel_padded_convolution(dtype):
     t = 1e-5 if dtype == torch.float32 else 1.5e-2
     assert relerr(y, yc) < t and relerr(ad.grad, ac.grad) < t and relerr(bd.grad, bc.grad) < t and relerr(wd.grad, wc.grad) < 2 * t
     assert tuple(wd.grad.shape) == (64, 304, 3, 3) and float(cat.grad[:, 304:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(4, 8, 64, 96, 96, 3, 2), (2, 64, 64, 64, 48, 3, 1), (2, 64, 128, 48, 48, 3, 1), (3, 64, 256, 24, 24, 1, 1)])
+def test_instance_norm_takes_its_statistics_from_the_convolution_epilogue(dtype, case):
+    """reference Resnet.py:534-536 / 176-178: the stem convolutions feed nn.InstanceNorm2d.  When no statistics row block of the
+    producing convolution straddles an image (H*W a multiple of the block height) its epilogue sums ARE the per-image partials:
+    the statistics pass over the convolution output is skipped.  Against the separate pass (same stored values, another summation
+    order): output, input gradient and weight gradients equal to fp32 rounding; a geometry whose blocks straddle images falls back."""
+    from mrfp_amd import conv
+    o = ops()
+    B, C, N, H, W, k, stride = case
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(N, C, k, k, generator=g) * 0.1
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    gy = torch.randn(B, N, Ho, Wo, generator=g)
+    res = []
+    for fused in (True, False):
+        o.IN_FUSED_STATS[0] = fused
+        o.IN_FUSED_HITS[0] = 0
+        try:
+            xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wd, gd, bd = w.to(DEV).requires_grad_(True), gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+            y = o.instance_norm_act(conv.conv2d(xd, wd, None, stride, k // 2, 1), gd, bd, relu=True)
+            y.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+            torch.cuda.synchronize()
+            res.append((y.detach().float().cpu(), xd.grad.float().cpu(), wd.grad.cpu(), gd.grad.cpu(), bd.grad.cpu(), o.IN_FUSED_HITS[0]))
+        finally:
+            o.IN_FUSED_STATS[0] = True
+    assert res[1][5] == 0
+    if dtype == torch.float32:
+        assert res[0][5] == 0                        # fp32 (parity mode) keeps the dedicated statistics pass
+    elif (Ho * Wo) % 192 == 0 and k == 3:
+        assert res[0][5] == 1                        # whatever tile the launch runs on (64- or 96-row blocks), no block straddles an image
+    # (the pointwise case runs on the persistent kernel, whose row blocks are workgroup tile ranges: they straddle images here -> fallback)
+    t = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(res[0][:5], res[1][:5]):
+        assert relerr(a, b) < t
+    if dtype == torch.float32:          # and against torch
+        yc = torch.relu(F.instance_norm(F.conv2d(x, w, None, stride, k // 2), weight=gamma, bias=beta))
+        assert relerr(res[0][0], yc) < 1e-4
