@@ -181,6 +181,21 @@ int mrfp_maxpool_fwd(const void* x, void* y, uint8_t* idx, int dtype,
 int mrfp_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype,
                      int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 
+/* The stem's  norm -> ReLU -> maxpool  (reference Resnet.py:549-551, 413-421; deepv3.py:309-315) without the normalised tensor in
+ * memory.  maxpool_affine_fwd pools relu(x*A + S) (A, S[C] or [B,C] as mrfp_affine_fwd; every window value is rounded to the
+ * activation type before the comparison, so y and idx are those of mrfp_affine_fwd followed by mrfp_maxpool_fwd).  The two
+ * backward passes of the normalisation take the POOLED gradient dy[B,Ho,Wo,C] + idx and x (the normalisation's input):
+ * pool_norm_bwd_stats writes the partial sums mrfp_stats_bwd would write for the un-pooled gradient (ws: [B][mrfp_stats_nslab(B,H)]
+ * [2][C] floats; ReLU gate (x*fA + fS) > 0), pool_norm_bwd_apply writes dx = P*d + Q*x + R as mrfp_affine_bwd does. */
+int mrfp_maxpool_affine_fwd(const void* x, const float* A, const float* S, int coef_per_image, int relu, void* y, uint8_t* idx,
+                            int dtype, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int mrfp_pool_norm_bwd_stats(const void* dy, const uint8_t* idx, const void* x, const float* mean, const float* fA,
+                             const float* fS, int coef_per_image, int relu, float* ws, int dtype,
+                             int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int mrfp_pool_norm_bwd_apply(const void* dy, const uint8_t* idx, const void* x, const float* P, const float* Q, const float* R,
+                             const float* fA, const float* fS, int coef_per_image, int relu, void* dx, int dtype,
+                             int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * CrossEntropyLoss(ignore_index=255), mean over valid pixels (reference main.py:822,
  * deepv3.py:363).  logits [B,H,W,C] NHWC (dtype), target int64 [B,H,W].

@@ -164,13 +164,26 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restr
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                uint8_t* __restrict__ idx, int B, int H, int W, int Ho,
-                                                               int Wo, int C, int ly) {
+                                                               int Wo, int C, int ly, const float* __restrict__ A,
+                                                               const float* __restrict__ S, int coef_per_image, int relu) {
+    // A != NULL: the pooled tensor is relu(x*A + S) (the apply pass of the normalisation in front of the pool, never stored):
+    // each window value goes through the arithmetic of affine_fwd_kernel and the rounding of its store before the comparison,
+    // so maxima AND arg-max positions are those of the two-kernel sequence
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
     const Lanes L = make_lanes(C, VEC);
     const int t = threadIdx.x;
     const int tcol = t % L.colthreads, trow = t / L.colthreads;
     if (trow >= L.rowthreads) return;
+    const bool aff = A != nullptr;
+    const size_t cbase = (size_t)(coef_per_image ? b : 0) * C;
     for (int cv = tcol; cv < L.lpr; cv += kThreads) {
+        float ca[VEC], cs[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { ca[i] = 1.f; cs[i] = 0.f; }
+        if (aff) {
+            load_coef<VEC>(A + cbase + (size_t)cv * VEC, ca);
+            load_coef<VEC>(S + cbase + (size_t)cv * VEC, cs);
+        }
         for (int oh = j; oh < Ho; oh += ly) {
             // TWO adjacent output columns per trip: their windows share the middle column pair, so 3 x 5 loads serve both
             // (3 x 3 each before: 17 % fewer vector loads, and two stores per trip)
@@ -203,6 +216,14 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restri
                         const bool inside = ih >= 0 && ih < H && iw >= 0 && iw < W;
                         float v[VEC];
                         cvt_f<T, VEC>(win[r * 5 + s], v);
+                        if (aff) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                float a = v[i] * ca[i] + cs[i];
+                                if (relu) a = a > 0.f ? a : 0.f;
+                                v[i] = to_f(from_f<T>(a));
+                            }
+                        }
                         if (s < 3) {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i)
@@ -232,6 +253,55 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restri
 
 // (gather over the 1-2 x 1-2 windows that contain the pixel; a variant with four unconditional candidate loads was
 //  measured slower: 403 vs 284 us at 16x384x384x128 -- it reads 1.8x the gradients)
+// gradient of the pool's INPUT at the two adjacent columns 2*ip, 2*ip + 1 of input row ih (image b, channel vector cv):
+// column 2k lies in output window k only, 2k+1 in k and k+1 -- the gradients and indices of outputs k, k+1 (nrow rows) are
+// loaded once for both, all in flight together
+template <typename T, int VEC>
+__device__ __forceinline__ void pool_grad_pair(const T* __restrict__ dy, const uint8_t* __restrict__ idx, int b, int ih, int ip,
+                                               int W, int Ho, int Wo, int C, int cv, float (&acc)[2][VEC]) {
+    const int oh0 = ih / 2, oh1 = (ih + 1) / 2;   // windows 2*oh-1 .. 2*oh+1 containing ih
+    const int nrow = (oh1 != oh0 && oh1 < Ho) ? 2 : 1;          // (uniform over the workgroup: ih is)
+    const int iw0 = 2 * ip;
+    const int owa = min(ip, Wo - 1), owb = min(ip + 1, Wo - 1);
+    VecT<T, VEC> dr[2][2];
+    VecT<uint8_t, VEC> pr[2][2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        if (rr < nrow) {
+            const size_t ol = ((size_t)b * Ho + (oh0 + rr)) * Wo * C + (size_t)cv * VEC;
+            dr[rr][0] = load_raw<T, VEC>(dy + ol + (size_t)owa * C);
+            dr[rr][1] = load_raw<T, VEC>(dy + ol + (size_t)owb * C);
+            pr[rr][0] = *reinterpret_cast<const VecT<uint8_t, VEC>*>(idx + ol + (size_t)owa * C);
+            pr[rr][1] = *reinterpret_cast<const VecT<uint8_t, VEC>*>(idx + ol + (size_t)owb * C);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        if (rr >= nrow) continue;
+        const int oh = oh0 + rr;
+        const int r = ih - (2 * oh - 1);                       // row of ih inside window oh
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {                       // output column ip + cc
+            const int ow = ip + cc;
+            float dv[VEC];
+            cvt_f<T, VEC>(dr[rr][cc], dv);
+            // input column iw0 + q sits at position s = iw0 + q - (2*ow - 1) of window ow (0 <= s <= 2 to belong)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sft = iw0 + q - (2 * ow - 1);
+                const bool in_win = ow < Wo && sft >= 0 && sft <= 2 && iw0 + q < W;
+                const uint8_t want = (uint8_t)(r * 3 + sft);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[q][i] += (in_win && pr[rr][cc].v[i] == want) ? dv[i] : 0.f;
+            }
+        }
+    }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                                T* __restrict__ dx, int B, int H, int W, int Ho, int Wo,
@@ -243,54 +313,108 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
     if (trow >= L.rowthreads) return;
     for (int cv = tcol; cv < L.lpr; cv += kThreads) {
         for (int ih = j; ih < H; ih += ly) {
-            const int oh0 = ih / 2, oh1 = (ih + 1) / 2;   // windows 2*oh-1 .. 2*oh+1 containing ih
-            const int nrow = (oh1 != oh0 && oh1 < Ho) ? 2 : 1;          // (uniform over the workgroup: ih is)
-            // TWO adjacent input columns (2k, 2k+1) per trip: column 2k lies in output window k only, 2k+1 in k and k+1 -- the
-            // gradients and indices of outputs k, k+1 (nrow rows) are loaded once for both, all in flight together
             for (int ip = trow; 2 * ip < W; ip += L.rowthreads) {
-                const int iw0 = 2 * ip;
-                const int owa = min(ip, Wo - 1), owb = min(ip + 1, Wo - 1);
-                VecT<T, VEC> dr[2][2];
-                VecT<uint8_t, VEC> pr[2][2];
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    if (rr < nrow) {
-                        const size_t ol = ((size_t)b * Ho + (oh0 + rr)) * Wo * C + (size_t)cv * VEC;
-                        dr[rr][0] = load_raw<T, VEC>(dy + ol + (size_t)owa * C);
-                        dr[rr][1] = load_raw<T, VEC>(dy + ol + (size_t)owb * C);
-                        pr[rr][0] = *reinterpret_cast<const VecT<uint8_t, VEC>*>(idx + ol + (size_t)owa * C);
-                        pr[rr][1] = *reinterpret_cast<const VecT<uint8_t, VEC>*>(idx + ol + (size_t)owb * C);
-                    }
-                }
                 float acc[2][VEC];
+                pool_grad_pair<T, VEC>(dy, idx, b, ih, ip, W, Ho, Wo, C, cv, acc);
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
+                    if (2 * ip + q < W) store_f<T, VEC>(dx + (((size_t)b * H + ih) * W + 2 * ip + q) * C + (size_t)cv * VEC, acc[q]);
+            }
+        }
+    }
+}
+
+// The backward passes of a normalisation (+ReLU) whose output only the pool reads (the stem: norm -> ReLU -> maxpool, reference
+// Resnet.py:549-551 / deepv3.py:309-315), taking the POOLED gradient: the gradient of the pool's input is rebuilt per pixel from the
+// (at most four) windows that contain it -- rounded to T, as maxpool_bwd_kernel stores it -- instead of being written by one kernel
+// and read back by these two.  x is the normalisation's input, the ReLU gate is (x*fA + fS) > 0 as in stats.hip / affine.hip.
+//   PASS 0: partial sums  s += d, q += d*(x - mean)  -> ws[blockIdx.x][2][C]   (rows as stats_kernel MODE 1 writes them)
+//   PASS 1: dx = P*d + (Q*x + R)
+template <typename T, int VEC, int PASS>
+__global__ __launch_bounds__(kThreads) void pool_norm_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                                 const T* __restrict__ x, T* __restrict__ dx,
+                                                                 float* __restrict__ ws, int B, int H, int W, int Ho, int Wo,
+                                                                 int C, int ly, const float* __restrict__ mean,
+                                                                 const float* __restrict__ fA, const float* __restrict__ fS,
+                                                                 const float* __restrict__ P, const float* __restrict__ Q,
+                                                                 const float* __restrict__ R, int coef_per_image, int relu) {
+    __shared__ float sm[PASS == 0 ? kThreads * 2 * VEC : 1];
+    const int b = blockIdx.x / ly, j = blockIdx.x % ly;
+    const Lanes L = make_lanes(C, VEC);
+    const int t = threadIdx.x;
+    const int tcol = t % L.colthreads, trow = t / L.colthreads;
+    const bool active = trow < L.rowthreads;
+    const size_t cbase = (size_t)(coef_per_image ? b : 0) * C;
+    for (int cv0 = 0; cv0 < L.lpr; cv0 += kThreads) {
+        const int cv = cv0 + tcol;
+        const bool on = active && cv < L.lpr;
+        float s[VEC], q2[VEC], mu[VEC], fa[VEC], fs[VEC], p[VEC], qq[VEC], r[VEC];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
+        for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q2[i] = 0.f; mu[i] = 0.f; fa[i] = 0.f; fs[i] = 1.f; p[i] = 1.f; qq[i] = 0.f; r[i] = 0.f; }
+        if (on) {
+            const size_t co = cbase + (size_t)cv * VEC;
+            if (relu) { load_coef<VEC>(fA + co, fa); load_coef<VEC>(fS + co, fs); }
+            if (PASS == 0) {
+                load_coef<VEC>(mean + co, mu);
+            } else {
+                load_coef<VEC>(P + co, p);
+                load_coef<VEC>(Q + co, qq);
+                load_coef<VEC>(R + co, r);
+            }
+            for (int ih = j; ih < H; ih += ly) {
+                const size_t sl = ((size_t)b * H + ih) * W * C + (size_t)cv * VEC;
+                for (int ip = trow; 2 * ip < W; ip += L.rowthreads) {
+                    const int iw1 = min(2 * ip + 1, W - 1);
+                    VecT<T, VEC> xr[2];
+                    if (PASS == 0) {        // (read again by PASS 1)
+                        xr[0] = load_raw<T, VEC>(x + sl + (size_t)(2 * ip) * C);
+                        xr[1] = load_raw<T, VEC>(x + sl + (size_t)iw1 * C);
+                    } else {
+                        xr[0] = load_raw_nt<T, VEC>(x + sl + (size_t)(2 * ip) * C);
+                        xr[1] = load_raw_nt<T, VEC>(x + sl + (size_t)iw1 * C);
+                    }
+                    float acc[2][VEC];
+                    pool_grad_pair<T, VEC>(dy, idx, b, ih, ip, W, Ho, Wo, C, cv, acc);
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    if (rr >= nrow) continue;
-                    const int oh = oh0 + rr;
-                    const int r = ih - (2 * oh - 1);                       // row of ih inside window oh
+                    for (int qd = 0; qd < 2; ++qd) {
+                        const bool inside = 2 * ip + qd < W;
+                        float xv[VEC], o[VEC];
+                        cvt_f<T, VEC>(xr[qd], xv);
 #pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {                       // output column ip + cc
-                        const int ow = ip + cc;
-                        float dv[VEC];
-                        cvt_f<T, VEC>(dr[rr][cc], dv);
-                        // input column iw0 + q sits at position s = iw0 + q - (2*ow - 1) of window ow (0 <= s <= 2 to belong)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int sft = iw0 + q - (2 * ow - 1);
-                            const bool in_win = ow < Wo && sft >= 0 && sft <= 2 && iw0 + q < W;
-                            const uint8_t want = (uint8_t)(r * 3 + sft);
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) acc[q][i] += (in_win && pr[rr][cc].v[i] == want) ? dv[i] : 0.f;
+                        for (int i = 0; i < VEC; ++i) {
+                            const float gate = xv[i] * fa[i] + fs[i];
+                            const float d = (inside && gate > 0.f) ? to_f(from_f<T>(acc[qd][i])) : 0.f;
+                            if (PASS == 0) {
+                                s[i] += d;
+                                q2[i] += d * (xv[i] - mu[i]);
+                            } else {
+                                o[i] = p[i] * d + (qq[i] * xv[i] + r[i]);
+                            }
                         }
+                        if (PASS == 1 && inside) store_f<T, VEC>(dx + sl + (size_t)(2 * ip + qd) * C, o);
                     }
                 }
+            }
+        }
+        if constexpr (PASS == 0) {
+            // combine the row-threads of each channel vector through LDS (as stats_kernel)
+            __syncthreads();
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    if (iw0 + q < W) store_f<T, VEC>(dx + (((size_t)b * H + ih) * W + iw0 + q) * C + (size_t)cv * VEC, acc[q]);
+            for (int i = 0; i < VEC; ++i) {
+                sm[(t * 2 + 0) * VEC + i] = s[i];
+                sm[(t * 2 + 1) * VEC + i] = q2[i];
+            }
+            __syncthreads();
+            float* out = ws + (size_t)blockIdx.x * 2 * C;
+            const int nout = L.colthreads * 2 * VEC;
+            for (int o = t; o < nout; o += kThreads) {
+                const int oc = o / (2 * VEC), rest = o % (2 * VEC);
+                if (cv0 + oc < L.lpr) {
+                    float a = 0.f;
+                    for (int rr = 0; rr < L.rowthreads; ++rr) a += sm[((rr * L.colthreads + oc) * 2) * VEC + rest];
+                    const int stat = rest / VEC, i = rest % VEC;
+                    out[(size_t)stat * C + (size_t)(cv0 + oc) * VEC + i] = a;
+                }
             }
         }
     }
@@ -347,12 +471,35 @@ static int do_bilinear_bwd(const void* dy, void* dx, int64_t B, int64_t Hi, int6
 }
 template <typename T>
 static int do_maxpool_fwd(const void* x, void* y, uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C,
-                          hipStream_t st) {
+                          hipStream_t st, const float* A = nullptr, const float* S = nullptr, int per_image = 0,
+                          int relu = 0) {
     const int Ho = (int)((H + 2 - 3) / 2 + 1), Wo = (int)((W + 2 - 3) / 2 + 1);
     const int ly = lines_per_image(B, Ho);
-    const bool ok = aligned16(x) && aligned16(y) && ((uintptr_t)idx % FullVec<T>::value) == 0;
+    const bool ok = aligned16(x) && aligned16(y) && ((uintptr_t)idx % FullVec<T>::value) == 0 &&
+                    (!A || (aligned16(A) && aligned16(S) && C % 4 == 0));
     DISPATCH_VEC(T, C, ok, maxpool_fwd_kernel, dim3((unsigned)(B * ly)), st, (const T*)x, (T*)y, idx, (int)B, (int)H,
-                 (int)W, Ho, Wo, (int)C, ly);
+                 (int)W, Ho, Wo, (int)C, ly, A, S, per_image, relu);
+    return 0;
+}
+template <typename T>
+static int do_pool_norm_bwd(int pass, const void* dy, const uint8_t* idx, const void* x, void* dx, float* ws, int64_t B,
+                            int64_t H, int64_t W, int64_t C, const float* mean, const float* fA, const float* fS,
+                            const float* P, const float* Q, const float* R, int per_image, int relu, hipStream_t st) {
+    const int Ho = (int)((H + 2 - 3) / 2 + 1), Wo = (int)((W + 2 - 3) / 2 + 1);
+    const int ly = lines_per_image(B, H);
+    bool ok = aligned16(dy) && aligned16(x) && (!dx || aligned16(dx)) && ((uintptr_t)idx % FullVec<T>::value) == 0 && C % 4 == 0;
+    for (const float* c : {mean, fA, fS, P, Q, R}) ok = ok && (!c || aligned16(c));
+    const dim3 grid((unsigned)(B * ly));
+#define MRFP_PNB(VECV, PASSV)                                                                                                  \
+    hipLaunchKernelGGL((pool_norm_bwd_kernel<T, VECV, PASSV>), grid, dim3(kThreads), 0, st, (const T*)dy, idx, (const T*)x,   \
+                       (T*)dx, ws, (int)B, (int)H, (int)W, Ho, Wo, (int)C, ly, mean, fA, fS, P, Q, R, per_image, relu)
+    if (pick_vec<T>(C) > 1 && ok) {
+        if (pass == 0) MRFP_PNB(FullVec<T>::value, 0); else MRFP_PNB(FullVec<T>::value, 1);
+    } else {
+        if (pass == 0) MRFP_PNB(1, 0); else MRFP_PNB(1, 1);
+    }
+#undef MRFP_PNB
+    MRFP_LAUNCH_CHECK();
     return 0;
 }
 template <typename T>
@@ -414,6 +561,40 @@ int mrfp_maxpool_fwd(const void* x, void* y, uint8_t* idx, int dtype, int64_t B,
     if (dtype == MRFP_BF16) return do_maxpool_fwd<bf16>(x, y, idx, B, H, W, C, (hipStream_t)stream);
     if (dtype == MRFP_F16) return do_maxpool_fwd<f16>(x, y, idx, B, H, W, C, (hipStream_t)stream);
     MRFP_CHECK(false, "maxpool_fwd: unknown dtype %d", dtype);
+}
+int mrfp_maxpool_affine_fwd(const void* x, const float* A, const float* S, int coef_per_image, int relu, void* y, uint8_t* idx,
+                            int dtype, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+    MRFP_CHECK(x && A && S && y && idx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_affine_fwd: bad arguments");
+    if (dtype == MRFP_F32) return do_maxpool_fwd<float>(x, y, idx, B, H, W, C, (hipStream_t)stream, A, S, coef_per_image, relu);
+    if (dtype == MRFP_BF16) return do_maxpool_fwd<bf16>(x, y, idx, B, H, W, C, (hipStream_t)stream, A, S, coef_per_image, relu);
+    if (dtype == MRFP_F16) return do_maxpool_fwd<f16>(x, y, idx, B, H, W, C, (hipStream_t)stream, A, S, coef_per_image, relu);
+    MRFP_CHECK(false, "maxpool_affine_fwd: unknown dtype %d", dtype);
+}
+int mrfp_pool_norm_bwd_stats(const void* dy, const uint8_t* idx, const void* x, const float* mean, const float* fA,
+                             const float* fS, int coef_per_image, int relu, float* ws, int dtype, int64_t B, int64_t H,
+                             int64_t W, int64_t C, void* stream) {
+    MRFP_CHECK(dy && idx && x && mean && ws && (!relu || (fA && fS)) && B > 0 && H > 0 && W > 0 && C > 0,
+               "pool_norm_bwd_stats: bad arguments");
+#define MRFP_PNS(TT) return do_pool_norm_bwd<TT>(0, dy, idx, x, nullptr, ws, B, H, W, C, mean, fA, fS, nullptr, nullptr, nullptr, \
+                                                 coef_per_image, relu, (hipStream_t)stream)
+    if (dtype == MRFP_F32) MRFP_PNS(float);
+    if (dtype == MRFP_BF16) MRFP_PNS(bf16);
+    if (dtype == MRFP_F16) MRFP_PNS(f16);
+#undef MRFP_PNS
+    MRFP_CHECK(false, "pool_norm_bwd_stats: unknown dtype %d", dtype);
+}
+int mrfp_pool_norm_bwd_apply(const void* dy, const uint8_t* idx, const void* x, const float* P, const float* Q, const float* R,
+                             const float* fA, const float* fS, int coef_per_image, int relu, void* dx, int dtype, int64_t B,
+                             int64_t H, int64_t W, int64_t C, void* stream) {
+    MRFP_CHECK(dy && idx && x && P && Q && R && dx && (!relu || (fA && fS)) && B > 0 && H > 0 && W > 0 && C > 0,
+               "pool_norm_bwd_apply: bad arguments");
+#define MRFP_PNA(TT) return do_pool_norm_bwd<TT>(1, dy, idx, x, dx, nullptr, B, H, W, C, nullptr, fA, fS, P, Q, R, coef_per_image, \
+                                                 relu, (hipStream_t)stream)
+    if (dtype == MRFP_F32) MRFP_PNA(float);
+    if (dtype == MRFP_BF16) MRFP_PNA(bf16);
+    if (dtype == MRFP_F16) MRFP_PNA(f16);
+#undef MRFP_PNA
+    MRFP_CHECK(false, "pool_norm_bwd_apply: unknown dtype %d", dtype);
 }
 int mrfp_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int64_t B, int64_t H, int64_t W,
                      int64_t C, void* stream) {

@@ -251,10 +251,8 @@ class _DeepLabBase(nn.Module):
         if not isinstance(trunk, (Resnet.ResNet, Resnet.ResNet3X3)):
             return trunk.stem(x), w_arr                # WiderResNet: mod1 -> pool2 -> mod2 -> pool3
         if isinstance(trunk, Resnet.ResNet3X3):
-            t = trunk.stem(x, w_arr)
-        else:
-            t = Resnet._norm_relu(self.layer0[1], trunk.wt_layer[2], self.layer0[0](ops.as_activation(x)), w_arr)
-        return ops.max_pool_3x3_s2(t), w_arr
+            return trunk.stem(x, w_arr), w_arr
+        return Resnet._norm_relu_pool(self.layer0[1], trunk.wt_layer[2], self.layer0[0](ops.as_activation(x)), w_arr), w_arr
 
     def _low(self, t, w_arr):
         """stem output -> low-level features (256 ch, 1/4): layer1 (reference deepv3.py:331-333) / mod3."""

@@ -49,6 +49,14 @@ def _norm_relu(layer, iw, x, w_arr):
     return ops.relu(layer(x))
 
 
+def _norm_relu_pool(layer, iw, x, w_arr):
+    """_norm_relu followed by the stem's MaxPool2d(3, 2, 1) (reference Resnet.py:549-551); an InstanceNorm there runs as one
+    operator with the pool."""
+    if iw not in (1, 2) and isinstance(layer, mynn.HipInstanceNorm2d):
+        return layer.fused_relu_pool(x)
+    return ops.max_pool_3x3_s2(_norm_relu(layer, iw, x, w_arr))
+
+
 class _Block(nn.Module):
     """Common tail of BasicBlock / Bottleneck: residual add, optional iw layer, ReLU."""
 
@@ -189,8 +197,7 @@ class ResNet(_Trunk):
 
     def forward(self, x):
         w_arr = []
-        x = _norm_relu(self.bn1, self.wt_layer[2], self.conv1(ops.as_activation(x)), w_arr)
-        x = ops.max_pool_3x3_s2(x)
+        x = _norm_relu_pool(self.bn1, self.wt_layer[2], self.conv1(ops.as_activation(x)), w_arr)
         return self._stages(x, w_arr)
 
 
@@ -213,14 +220,14 @@ class ResNet3X3(_Trunk):
         self._finish(block, layers, wt_layer, num_classes)
 
     def stem(self, x, w_arr):
+        """conv-norm-ReLU x 3 and the max pool."""
         x = _norm_relu(self.bn1, self.wt_layer[0], self.conv1(ops.as_activation(x)), w_arr)
         x = _norm_relu(self.bn2, self.wt_layer[1], self.conv2(x), w_arr)
-        return _norm_relu(self.bn3, self.wt_layer[2], self.conv3(x), w_arr)
+        return _norm_relu_pool(self.bn3, self.wt_layer[2], self.conv3(x), w_arr)
 
     def forward(self, x):
         w_arr = []
-        x = ops.max_pool_3x3_s2(self.stem(x, w_arr))
-        return self._stages(x, w_arr)
+        return self._stages(self.stem(x, w_arr), w_arr)
 
 
 def _maybe_pretrained(model, name, pretrained):

@@ -54,6 +54,10 @@ class HipInstanceNorm2d(nn.InstanceNorm2d):
     def fused(self, x, *, relu=False):
         return ops.instance_norm_act(x, self.weight, self.bias, eps=self.eps, relu=relu, emit_stats=self._emit_plane_stats)
 
+    def fused_relu_pool(self, x):
+        """ReLU and the 3x3 / stride 2 max pool behind this layer, in one operator (the stem: ops.instance_norm_relu_pool)."""
+        return ops.instance_norm_relu_pool(x, self.weight, self.bias, eps=self.eps)
+
     def forward(self, x):
         return self.fused(x)
 

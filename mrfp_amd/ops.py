@@ -437,34 +437,41 @@ IN_FUSED_STATS = [os.environ.get("MRFP_IN_FUSED_STATS", "1") != "0"]     # Insta
 IN_FUSED_HITS = [0]
 
 
+def _in_plane_sums(x):
+    """-> (x checked, nslab, ws): the [B][nslab][2][C] partial (sum, sum of squares) rows of x's planes for mrfp_in_finalize, from
+    whoever already has them -- the producing convolution's epilogue, the producing apply pass -- or a statistics pass."""
+    ps = _take_planestats(x)
+    x = _chk(x)
+    B, C, H, W = x.shape
+    fused = getattr(x, "_mrfp_colstats", None)
+    # (16-bit activations only: behind the stem convolutions a channel's mean is tens of its standard deviations -- inputs are
+    #  0..255 -- and the fp32 parity criteria of the ill-conditioned fixture resolve the SUMMATION ORDER of its statistics:
+    #  with the epilogue's sums the stem weight gradient of mrfp_c1 moved 0.37 from fp64 where 3x the reference's own fp32
+    #  distance allows 0.19; bf16 storage rounds 10^4 times coarser than that)
+    if (IN_FUSED_STATS[0] and x.element_size() == 2 and fused is not None and len(fused) >= 6 and fused[2] == B * H * W and fused[5] > 0
+            and (H * W) % fused[5] == 0 and B * ((H * W) // fused[5]) <= fused[4] and fused[3].numel() >= fused[4] * 2 * C):
+        # the producing convolution summed its output per row block in its epilogue, and no row block straddles an image
+        # (H*W is a multiple of the block height): its rows ARE the [B][blocks per image][2][C] partials of the plane sums --
+        # the statistics pass over the convolution output disappears
+        IN_FUSED_HITS[0] += 1
+        return x, (H * W) // fused[5], fused[3]
+    if ps is not None:
+        return x, ps[0], ps[1]
+    nslab, ws = _stats_fwd(x, None)
+    return x, nslab, ws
+
+
 class _InstanceNormAct(torch.autograd.Function):
     """nn.InstanceNorm2d(affine) (+ReLU): reference Resnet.py:176-178, 218-225, 534-536."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, relu, emit_stats=False):
-        ps = _take_planestats(x)
-        x = _chk(x)
+        x, nslab, ws = _in_plane_sums(x)
         B, C, H, W = x.shape
         w32, b32 = _f32(weight), _f32(bias)
         coef = torch.empty(4 * B * C, dtype=torch.float32, device=x.device)
         n = B * C
         mean, invstd, A, S = coef[0:n], coef[n:2 * n], coef[2 * n:3 * n], coef[3 * n:4 * n]
-        fused = getattr(x, "_mrfp_colstats", None)
-        # (16-bit activations only: behind the stem convolutions a channel's mean is tens of its standard deviations -- inputs are
-        #  0..255 -- and the fp32 parity criteria of the ill-conditioned fixture resolve the SUMMATION ORDER of its statistics:
-        #  with the epilogue's sums the stem weight gradient of mrfp_c1 moved 0.37 from fp64 where 3x the reference's own fp32
-        #  distance allows 0.19; bf16 storage rounds 10^4 times coarser than that)
-        if (IN_FUSED_STATS[0] and x.element_size() == 2 and fused is not None and len(fused) >= 6 and fused[2] == B * H * W and fused[5] > 0
-                and (H * W) % fused[5] == 0 and B * ((H * W) // fused[5]) <= fused[4] and fused[3].numel() >= fused[4] * 2 * C):
-            # the producing convolution summed its output per row block in its epilogue, and no row block straddles an image
-            # (H*W is a multiple of the block height): its rows ARE the [B][blocks per image][2][C] partials of the plane sums --
-            # the statistics pass over the convolution output (the three stem layers: 1.2 GB per step) disappears
-            nslab, ws = (H * W) // fused[5], fused[3]
-            IN_FUSED_HITS[0] += 1
-        elif ps is not None:
-            nslab, ws = ps
-        else:
-            nslab, ws = _stats_fwd(x, None)
         call("mrfp_in_finalize", ptr(ws), B, nslab, H * W, C, ptr(w32), ptr(b32), float(eps), ptr(mean),
              ptr(invstd), ptr(A), ptr(S), stream())
         y = _affine_fwd(x, None, A, S, True, relu, None, emit_stats=emit_stats)
@@ -651,6 +658,77 @@ class _MaxPool(torch.autograd.Function):
 
 def max_pool_3x3_s2(x):
     return _MaxPool.apply(x)
+
+
+POOL_FUSED = [os.environ.get("MRFP_POOL_FUSED", "1") != "0"]
+POOL_FUSED_HITS = [0]
+
+
+class _InstanceNormReluPool(torch.autograd.Function):
+    """InstanceNorm2d -> ReLU -> MaxPool2d(3, 2, 1) as ONE operator: the stem of the trunks whose wt_layer selects an
+    instance norm there (reference Resnet.py:176-178, 549-551; deepv3.py:309-315).  The normalised tensor is never stored: the
+    pool applies x*A + S and the ReLU to its window values (mrfp_maxpool_affine_fwd), and the two backward passes of the
+    normalisation rebuild the gradient of the pool's input from the pooled gradient and the arg-max positions
+    (mrfp_pool_norm_bwd_stats / _apply) -- per step one write and three reads of the largest activation of the network less.
+    Results are those of instance_norm_act(relu=True) + max_pool_3x3_s2 (statistics: same kernels; maxima / positions: same values,
+    rounded before the comparison; backward sums in a different order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x, nslab, ws = _in_plane_sums(x)
+        B, C, H, W = x.shape
+        w32, b32 = _f32(weight), _f32(bias)
+        n = B * C
+        coef = torch.empty(4 * n, dtype=torch.float32, device=x.device)
+        mean, invstd, A, S = coef[0:n], coef[n:2 * n], coef[2 * n:3 * n], coef[3 * n:4 * n]
+        call("mrfp_in_finalize", ptr(ws), B, nslab, H * W, C, ptr(w32), ptr(b32), float(eps), ptr(mean),
+             ptr(invstd), ptr(A), ptr(S), stream())
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = empty_cl(B, C, Ho, Wo, x.dtype, x.device)
+        idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+        call("mrfp_maxpool_affine_fwd", ptr(x), ptr(A), ptr(S), 1, 1, ptr(y), ptr(idx), dt(x), B, H, W, C, stream())
+        ctx.affine = weight is not None
+        ctx.wparam, ctx.bparam = weight, bias
+        ctx.save_for_backward(x, idx, w32, mean, invstd, A, S)
+        POOL_FUSED_HITS[0] += 1
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, idx, w32, mean, invstd, A, S = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        B, C, H, W = x.shape
+        nslab, ws = _stats_ws(B, H, C, x.device)
+        call("mrfp_pool_norm_bwd_stats", ptr(dy), ptr(idx), ptr(x), ptr(mean), ptr(A), ptr(S), 1, 1, ptr(ws), dt(x), B, H, W, C,
+             stream())
+        n = B * C
+        pqr = torch.empty(3 * n, dtype=torch.float32, device=dy.device)
+        P, Q, R = pqr[0:n], pqr[n:2 * n], pqr[2 * n:3 * n]
+        dwb = torch.empty(2 * C, dtype=torch.float32, device=dy.device)
+        sw = grad_sink(ctx.wparam) if ctx.affine else None
+        sb = grad_sink(ctx.bparam) if ctx.affine else None
+        call("mrfp_in_bwd_finalize", ptr(ws), B, nslab, H * W, C, ptr(w32), ptr(mean), ptr(invstd),
+             ptr(sw if sw is not None else dwb[:C]), ptr(sb if sb is not None else dwb[C:]), ptr(P), ptr(Q), ptr(R), stream())
+        dx = empty_cl(B, C, H, W, dy.dtype, dy.device)
+        call("mrfp_pool_norm_bwd_apply", ptr(dy), ptr(idx), ptr(x), ptr(P), ptr(Q), ptr(R), ptr(A), ptr(S), 1, 1, ptr(dx), dt(x),
+             B, H, W, C, stream())
+        if not ctx.affine:
+            return dx, None, None, None
+        dw, db = dwb[:C], dwb[C:]
+        if sw is not None:
+            notify_grad(ctx.wparam)
+            dw = None
+        if sb is not None:
+            notify_grad(ctx.bparam)
+            db = None
+        return dx, dw, db, None
+
+
+def instance_norm_relu_pool(x, weight, bias, *, eps=1e-5):
+    """instance_norm_act(relu=True) followed by max_pool_3x3_s2, fused (MRFP_POOL_FUSED=0: the two operators)."""
+    if not POOL_FUSED[0]:
+        return max_pool_3x3_s2(instance_norm_act(x, weight, bias, eps=eps, relu=True))
+    return _InstanceNormReluPool.apply(x, weight, bias, eps)
 
 
 # ------------------------------------------------------------------------------------------

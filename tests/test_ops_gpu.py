@@ -245,6 +245,55 @@ def test_maxpool(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (2, 64, 17, 13), (3, 128, 24, 40), (1, 8, 1, 1), (2, 19, 7, 6), (2, 2048, 4, 5)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_instance_norm_relu_pool_is_the_two_operator_sequence(dtype, shape, affine):
+    """The stem's norm -> ReLU -> maxpool as one operator (reference Resnet.py:549-551): same output bits as
+    instance_norm_act(relu=True) + max_pool_3x3_s2 (each window value rounded before the comparison), same gradient routing;
+    the fp32 run is also held against torch."""
+    o = ops()
+    B, C, H, W = shape
+    x = rnd(*shape, seed=41, scale=50.0, shift=120.0)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    w, b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    outs = []
+    hits = o.POOL_FUSED_HITS[0]
+    for fused in (True, False):
+        o.POOL_FUSED[0] = fused
+        try:
+            xd = dev(x, dtype)
+            wd = w.to(DEV).requires_grad_(True) if affine else None
+            bd = b.to(DEV).requires_grad_(True) if affine else None
+            yd = o.instance_norm_relu_pool(xd, wd, bd)
+            gy = rnd(*yd.shape, seed=42)
+            yd.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+            outs.append((yd.detach(), xd.grad, wd.grad if affine else None, bd.grad if affine else None))
+        finally:
+            o.POOL_FUSED[0] = True
+    assert o.POOL_FUSED_HITS[0] == hits + 1
+    (yf, gxf, gwf, gbf), (yu, gxu, gwu, gbu) = outs
+    assert torch.equal(yf, yu)
+    t = tol(dtype)
+    # the un-pooled gradient is rebuilt with the rounding maxpool_bwd stores it with: the two paths differ by the summation order
+    # of the backward statistics only
+    assert relerr(gxf, gxu) < (1e-5 if dtype == torch.float32 else 1e-2)
+    if affine:
+        assert relerr(gwf, gwu) < 1e-4 and relerr(gbf, gbu) < 1e-4
+    xc = x.clone().requires_grad_(True)
+    wc = w.clone().requires_grad_(True) if affine else None
+    bc = b.clone().requires_grad_(True) if affine else None
+    yc = F.max_pool2d(F.relu(F.instance_norm(xc, None, None, wc, bc, True, 0.1, 1e-5)), 3, 2, 1) if H * W > 1 else None
+    if yc is not None:
+        yc.backward(rnd(*yc.shape, seed=42))
+        assert relerr(yf, yc) < t * (1 if dtype == torch.float32 else 2)
+        if dtype == torch.float32:
+            assert relerr(gxf, xc.grad) < 20 * t
+            if affine:
+                assert relerr(gwf, wc.grad) < 10 * t and relerr(gbf, bc.grad) < 10 * t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_global_avg_pool_add_relu(dtype):
     o = ops()
     x = rnd(2, 256, 7, 9, seed=18)
