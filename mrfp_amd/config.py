@@ -58,6 +58,11 @@ cfg.MODEL.COMMUTE_O2 = __import__("os").environ.get("MRFP_COMMUTE_O2", "1") != "
 # 304; the 304-channel weight of final1[0] is zero-padded in its packs, the state_dict keeps the reference shape) so that its
 # K dimension is whole 128-byte tiles -- aligned / row-reuse convolution kernels instead of the per-thread tap tracking of the
 # unaligned ones.  1 = the reference's 304.
+# HRFP_LAZY (off = the reference's behaviour, deepv3.py:320-327: the HRFP branch runs in every forward): run only the part of the
+# branch whose output the step reads -- none of it when neither O1 nor O2 is drawn, its first four layers when only O2 is.  Loss,
+# gradients and every trainable tensor are unchanged; the BatchNorm running statistics of the (frozen, re-randomised) OC* layers
+# -- buffers no output of the network depends on, in train or eval mode -- are then only updated by the passes that run.
+cfg.MODEL.HRFP_LAZY = __import__("os").environ.get("MRFP_HRFP_LAZY", "0") == "1"
 cfg.MODEL.DECODER_PAD = int(__import__("os").environ.get("MRFP_DECODER_PAD", "64"))
 # BatchNorm statistics summed over all ranks of the default process group (reference config.py:92-93, torch.nn.SyncBatchNorm).
 # Off: with 16 images per GPU the per-replica statistics ARE the reference's single-GPU population.

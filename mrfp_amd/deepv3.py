@@ -369,10 +369,13 @@ class MRFPPlus(_DeepLabBase):
         alpha, beta_noise = self.rng.np_noise(which, B, C, feat.device)
         return ops.np_plus(feat, alpha, beta_noise, res)
 
-    def _hrfp(self, xp, h, w):
+    def _hrfp(self, xp, h, w, need_out=True, need_dec=True):
         """reference deepv3.py:320-327: conv -> nearest resize -> BN(train stats) -> ReLU, x8.  The resize
         is never materialised on its own: BN statistics and apply read the conv output through the
-        nearest index tables."""
+        nearest index tables.  need_out / need_dec (cfg.MODEL.HRFP_LAZY only): whether OCout / OCout_dec are read."""
+        lazy = cfg.MODEL.HRFP_LAZY and self._taps is None
+        if lazy and not (need_out or need_dec):
+            return None, None, xp
         resize = [dict(scale=1.205), dict(scale=1.2), dict(scale=1.2), dict(size=(int(h / 2), int(w / 2))),
                   dict(size=(int(h / 2), int(w / 2))), dict(scale=0.838), dict(scale=0.798),
                   dict(size=(math.ceil(h / 4), math.ceil(w / 4)))]
@@ -381,6 +384,8 @@ class MRFPPlus(_DeepLabBase):
             if i == 0:            # xp also feeds the trunk: the trunk-side gradient rides in this conv's dgrad epilogue
                 t, xp_alias = conv.forward_skip(t)
             elif i == 4:          # OCout_dec also feeds the O2 add: same chaining
+                if lazy and not need_out:
+                    return t, None, xp_alias
                 t, dec = conv.forward_skip(t)
             else:
                 t = conv(t)
@@ -407,7 +412,7 @@ class MRFPPlus(_DeepLabBase):
             else:                               # a single perturb.FourierAmplitudeMix at the stem
                 xp = fp(xp)
         self._tap("stem", xp)
-        OCout_dec, OCout, xp = self._hrfp(xp, h, w)   # always computed, as the reference does (no RNG inside)
+        OCout_dec, OCout, xp = self._hrfp(xp, h, w, o1, o2)   # always computed, as the reference does (no RNG inside), unless HRFP_LAZY
         t = xp
         if npp and o1 and self._taps is None:
             # NP+(xp) + OCout in ONE pass (the per-stage taps of the parity tests want the intermediate: they take the two-pass form)

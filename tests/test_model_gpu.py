@@ -308,6 +308,36 @@ def test_hrfp_reinitialisation_arena_matches_the_reference_initialiser():
         cfg.MODEL.ACT_DTYPE = torch.float32
 
 
+@pytest.mark.parametrize("toggles", [(False, True, False), (False, False, True), (True, True, True)])
+def test_lazy_hrfp_changes_no_loss_and_no_gradient(toggles):
+    """cfg.MODEL.HRFP_LAZY: the part of the HRFP branch (reference deepv3.py:320-327) whose output the step does not read is not
+    run.  Loss and every gradient must be those of the full branch (the branch has no RNG and no trainable tensor)."""
+    from mrfp_amd.config import cfg
+    from mrfp_amd.deepv3 import InjectedRandom
+    x, y = synth.synth_batch(2, 256, 256, seed=1)
+    noise = synth.synth_noise(2, seed=2)
+    res = []
+    for lazy in (False, True):
+        cfg.MODEL.HRFP_LAZY = lazy
+        try:
+            model, _ = build_model("hip")
+            model.train()
+            model.rng = InjectedRandom(toggles, noise)
+            before = int(model.state_dict()["OC1_bn.num_batches_tracked"])
+            loss = model(x.to(DEV), y.to(DEV), training=True)
+            loss.backward()
+            res.append((loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+                        int(model.state_dict()["OC1_bn.num_batches_tracked"]) - before))
+        finally:
+            cfg.MODEL.HRFP_LAZY = False
+    (l0, g0, n0), (l1, g1, n1) = res
+    assert l0 == l1
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert n0 == 1 and n1 == (1 if (toggles[0] or toggles[2]) else 0)     # the only visible difference: an unused pass updates no buffer
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_plane_statistics_from_the_producing_apply_pass_are_bit_identical(dtype):
     """mrfp_affine_fwd_stats: the residual tails in front of the two InstanceNorm `iw` taps (reference Resnet.py:218-225) and the
