@@ -330,8 +330,8 @@ def _eager_step(trainer, x, y):
 #     sizeof x (tensor operands the launch reads or writes), from the launch arguments.
 #   * with --fourier: the build-defined Fourier amplitude mix (3 planes per call: x, the partner, y).
 # ---------------------------------------------------------------------------------------------------------------------
-CONV_CALLS = ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_wgrad", "mrfp_conv_wgrad_grouped")
-NORM_CALLS = ("mrfp_stats_fwd", "mrfp_stats_bwd", "mrfp_stats_bwd_mask", "mrfp_affine_fwd", "mrfp_affine_bwd",
+CONV_CALLS = ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_fwd_wstats", "mrfp_conv_wgrad", "mrfp_conv_wgrad_grouped")
+NORM_CALLS = ("mrfp_maxpool_affine_fwd", "mrfp_pool_norm_bwd_stats", "mrfp_pool_norm_bwd_apply", "mrfp_stats_fwd", "mrfp_stats_bwd", "mrfp_stats_bwd_mask", "mrfp_affine_fwd", "mrfp_affine_bwd",
               "mrfp_affine_fwd_relu_mask", "mrfp_affine_bwd_mask", "mrfp_bn_finalize", "mrfp_bn_bwd_finalize", "mrfp_in_finalize",
               "mrfp_in_bwd_finalize", "mrfp_np_finalize", "mrfp_np_bwd_finalize", "mrfp_mean_finalize", "mrfp_bn_eval_coef",
               "mrfp_copy_channels")
@@ -345,12 +345,12 @@ def _family(name):
 
 def _launch_work(name, d, esz):
     """(algorithmic FLOP, algorithmic bytes) of one launch from its named arguments."""
-    if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated"):
+    if name in ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_fwd_wstats"):
         # ALGORITHMIC work: the logical channel counts (the zero channels of a padded buffer -- network input 3 -> 8, decoder
         # concatenation 304 -> 320 -- are not work); conv.py reports them through _lib.NOTE, absent = the physical counts
         M = d["B"] * d["Ho"] * d["Wo"]
         C, N = d.get("Clog", d["C"]), d.get("Nlog", d["N"])
-        flop = 2.0 * M * N * d["R"] * d["S"] * C / float(d["sstride"] * d["sstride"])
+        flop = 2.0 * M * N * d["R"] * d["S"] * C / float(d.get("sstride", 1) ** 2)
         byts = esz * (d["B"] * d["H"] * d["W"] * C + M * N + N * d["R"] * d["S"] * C
                       + (M * N if d.get("addend") else 0)) + (M * N / 8.0 if d.get("addend_mask") else 0)
         return flop, byts
@@ -414,8 +414,11 @@ def step_roofline(model, trainer, x, y, args):
             if fam == "conv":
                 wg = name in ("mrfp_conv_wgrad", "mrfp_conv_wgrad_grouped")
                 first = _lib.ARG_NAMES[name].index("B")
+                shape = [int(d[k]) for k in _lib.ARG_NAMES[name][first:first + 15]]
+                if name == "mrfp_conv_fwd_wstats":          # (no sstride argument: 14 geometry values + sstride 1)
+                    shape = shape[:14] + [1]
                 convs.append({"name": "mrfp_conv_wgrad" if wg else "mrfp_conv_fwd", "ms": ms, "flop": fl, "bytes": by,
-                              "group": int(d.get("count", 1)), "args": [int(d[k]) for k in _lib.ARG_NAMES[name][first:first + 15]]})
+                              "group": int(d.get("count", 1)), "args": shape})
     if args.dump_launches:      # an event in front of EVERY launch (inflates the few-microsecond kernels: a diagnostic, not the bench line)
         rows = []
         for i, (e, fam, calls) in enumerate(marks):

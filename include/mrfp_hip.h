@@ -277,6 +277,14 @@ int mrfp_conv_single_launch(int64_t B, int64_t image_bytes);
 int64_t mrfp_conv_stats_rows(int64_t nblk);
 int64_t mrfp_conv_stats_final_first(int64_t nblk);
 int64_t mrfp_conv_stats_final_count(int64_t nblk);
+/* mrfp_conv_fwd whose fused statistics count output row m (pixel b, oh, ow) `rowweight[m]` times: the statistics of the
+ * nearest-neighbour RESIZED output (rowweight = the pixel's multiplicity in the resize, 0..255) -- the HRFP stages
+ * conv -> F.interpolate(nearest) -> BatchNorm(train) (reference deepv3.py:320-327) without a statistics pass over the
+ * resized tensor.  rowweight: 4-byte aligned, B*Ho*Wo bytes + 256 readable bytes of padding.  Not for pointwise convolutions. */
+int mrfp_conv_fwd_wstats(const void* x, const void* wpack, const float* bias, void* y, int dtype,
+                         int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S,
+                         int64_t Ho, int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil,
+                         const uint8_t* rowweight, float* colstats, void* stream);
 /* mrfp_conv_fwd with a GATED addend: y = conv(x) + (addend where its gate bit is set, else 0).  addend_mask holds one bit per
  * element of the dense [M][N] addend (bit e & 7 of byte e >> 3, e = m*N + n) -- the sign mask mrfp_affine_fwd_relu_mask wrote for
  * the residual tail whose incoming gradient `addend` is: the skip-connection gradient dy * [y > 0] (reference: autograd of

@@ -20,6 +20,12 @@ _PACKS = {}      # id(weight Parameter) -> {key: _Pack}; entry dropped when the 
 import os as _os
 FUSE_STATS = [_os.environ.get("MRFP_FUSE_STATS", "1") != "0"]   # conv epilogues emit BatchNorm partial statistics for bias-free convolutions
 _LAST_STATS = [None]  # handed from _Conv2d.forward to conv2d() (autograd re-wraps the output tensor object)
+# set by a caller right before a convolution whose output goes through a nearest-neighbour resize into a training-mode BatchNorm
+# (deepv3.MRFPPlus._hrfp): the ops.NearestPlan of that resize.  The epilogue statistics then count every output pixel as often as
+# the resize reads it (mrfp_conv_fwd_wstats), and the BatchNorm skips its statistics pass over the resized tensor.
+STAT_RESIZE = [None]
+WSTATS = [_os.environ.get("MRFP_WSTATS", "1") != "0"]
+WSTATS_HITS = [0]
 _EPOCH = [0]     # bumped by writers that bypass autograd's version counters (the fused SGD kernel)
 
 
@@ -394,19 +400,34 @@ class _Conv2d(torch.autograd.Function):
         y = empty_cl(B, Nphys, Ho, Wo, x.dtype, x.device)
         stats = None
         L = _lib.lib()
-        if bias is None and FUSE_STATS[0] and L.mrfp_conv_single_launch(B, H * W * Cphys * x.element_size()):
+        plan, STAT_RESIZE[0] = STAT_RESIZE[0], None
+        single = bool(L.mrfp_conv_single_launch(B, H * W * Cphys * x.element_size()))
+        wtab = None
+        if plan is not None and WSTATS[0] and FUSE_STATS[0] and single and (plan.Hs, plan.Ws) == (Ho, Wo) and R * S > 1:
+            wtab = plan.multiplicity(B)          # statistics of the nearest-resized output (see STAT_RESIZE)
+        if wtab is not None or (bias is None and FUSE_STATS[0] and single):
             # no bias = a convolution that feeds a normalisation layer: let the epilogue produce its statistics
             nblk = int(L.mrfp_conv_stats_blocks(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1))
             stats = torch.empty(int(L.mrfp_conv_stats_rows(nblk)) * 2 * Nphys, dtype=torch.float32, device=x.device)
         _lib.NOTE[0] = (C, N)
-        call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
-             Ho, Wo, stride, pad_h, pad_w, dil, 1, None, ptr(stats), stream())
+        if wtab is not None:
+            call("mrfp_conv_fwd_wstats", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
+                 Ho, Wo, stride, pad_h, pad_w, dil, ptr(wtab), ptr(stats), stream())
+            WSTATS_HITS[0] += 1
+        else:
+            call("mrfp_conv_fwd", ptr(x), ptr(pk.wf), ptr(pk.bias), ptr(y), dt(x), B, H, W, Cphys, Nphys, Nphys, R, S,
+                 Ho, Wo, stride, pad_h, pad_w, dil, 1, None, ptr(stats), stream())
         if stats is not None:      # the rows the BatchNorm finalize should read (compacted for large launches)
             first, cnt = int(L.mrfp_conv_stats_final_first(nblk)), int(L.mrfp_conv_stats_final_count(nblk))
-            # (rows to hand to a BatchNorm finalize, their count, the element count; + the RAW per-row-block rows and their count: an
-            #  InstanceNorm consumer needs them per image -- ops._InstanceNormAct)
-            rb = int(L.mrfp_conv_stats_block_rows(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1))
-            _LAST_STATS[0] = (stats[first * 2 * Nphys:(first + cnt) * 2 * Nphys], cnt, B * Ho * Wo, stats, nblk, rb)
+            final = stats[first * 2 * Nphys:(first + cnt) * 2 * Nphys]
+            if wtab is not None:
+                # (element count = that of the RESIZED tensor; no per-image use; the plan identifies the one consumer they serve)
+                _LAST_STATS[0] = (final, cnt, B * plan.Ho * plan.Wo, stats, nblk, 0, plan)
+            else:
+                # (rows to hand to a BatchNorm finalize, their count, the element count; + the RAW per-row-block rows and their count:
+                #  an InstanceNorm consumer needs them per image -- ops._InstanceNormAct)
+                rb = int(L.mrfp_conv_stats_block_rows(dt(x), B, H, W, Cphys, Nphys, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1))
+                _LAST_STATS[0] = (final, cnt, B * Ho * Wo, stats, nblk, rb)
         else:
             _LAST_STATS[0] = None
         ctx.save_for_backward(x, weight, bias)

@@ -151,7 +151,11 @@ inline int lines_per_image(int64_t B, int64_t Ho) {
     }
     int64_t cap = total / (B > 0 ? B : 1);
     if (cap < 1) cap = 1;
-    return (int)(Ho < cap ? Ho : cap);
+    if (Ho <= cap) return (int)Ho;
+    // every workgroup the same number of lines (the last few one less): 192 lines over 128 workgroups gave half of them two lines and
+    // half one -- the launch ran as long as the two-line workgroups (round 4: 96 x 2 lines, normalisation family -0.3 ms per step)
+    const int64_t per = (Ho + cap - 1) / cap;
+    return (int)((Ho + per - 1) / per);
 }
 
 }  // namespace mrfp

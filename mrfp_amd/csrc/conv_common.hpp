@@ -68,6 +68,9 @@ struct ConvP {
                         // taken as 0 where the bit is clear -- the ReLU gate of a residual tail applied while its gradient is
                         // added (16-bit types, N % 8 == 0, dense ldy)
     float* colstats;    // [row blocks][2][ldy] per-channel sum / sum of squares of the stored output, or null
+    const unsigned char* rowweight;     // or null: [M rounded up to the tile height] one byte per output row (pixel): the statistics count
+                        // that row `rowweight[m]` times -- the multiplicity of the pixel in a nearest-neighbour resize of the output
+                        // (the HRFP stages, reference deepv3.py:320-327: the BatchNorm behind the resize takes its statistics from here)
     int B, H, W, C;
     int N, ldy;
     int R, S, Ho, Wo;

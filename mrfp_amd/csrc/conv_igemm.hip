@@ -395,11 +395,27 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
         cs[j] = 0.f;
         cq[j] = 0.f;
     }
+    // statistics weights of this lane's rows: four consecutive rows per 32-bit load (the table is padded to whole tiles and 4-byte
+    // aligned, every group of four rows starts at a multiple of 4), kept packed.  `wmode` is uniform: tiles without a table that lie
+    // wholly inside the output (all but the last row tile of every BatchNorm convolution outside the HRFP branch) take the plain
+    // sums -- convert, add, multiply-add per element; the others multiply by the row's weight (0 for rows past M)
+    const bool wst = p.colstats && p.rowweight;
+    const bool wmode = p.colstats && (wst || m0 + WM * 32 * TM > p.M);
+    unsigned rwp[M16 ? 2 * TM : 4 * TM];
+#pragma unroll
+    for (int g = 0; g < (M16 ? 2 * TM : 4 * TM); ++g) {
+        const int r0 = M16 ? g * 16 + 4 * lq : (g >> 2) * 32 + 8 * (g & 3) + 4 * lh;
+        rwp[g] = wst ? *reinterpret_cast<const unsigned*>(p.rowweight + (m0 + wm * 32 * TM + r0)) : 0x01010101u;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if constexpr (M16) {
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
+            for (int i2 = 0; i2 < 2; ++i2) {
+                float w4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    w4[e] = (m0 + wm * 32 * TM + i * 32 + i2 * 16 + 4 * lq + e < p.M) ? (float)((rwp[2 * i + i2] >> (8 * e)) & 0xffu) : 0.f;
 #pragma unroll
                 for (int j = 0; j < 2 * TN; ++j)
 #pragma unroll
@@ -408,25 +424,44 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
                         const T sv = from_f<T>(acc16[2 * i + i2][j][e] + bv[j]);
                         *reinterpret_cast<T*>(ep + row * EPITCH + (j * 16 + l15) * (int)sizeof(T)) = sv;
                         if (p.colstats) {
-                            const float fv = (m0 + wm * 32 * TM + i * 32 + row < p.M) ? to_f(sv) : 0.f;
+                            const float fv = to_f(sv);
+                            if (wmode) {
+                                const float wf = fv * w4[e];
+                                cs[j] += wf;
+                                cq[j] += wf * fv;
+                            } else {
+                                cs[j] += fv;
+                                cq[j] += fv * fv;
+                            }
+                        }
+                    }
+            }
+        } else {
+            float w16[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                w16[e] = (m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh < p.M)
+                             ? (float)((rwp[M16 ? 0 : 4 * i + (e >> 2)] >> (8 * (e & 3))) & 0xffu) : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const T sv = from_f<T>(acc[i][j][e] + bv[j]);
+                    *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = sv;
+                    if (p.colstats) {      // BatchNorm statistics of the STORED (rounded) values, fused into the producer
+                        const float fv = to_f(sv);
+                        if (wmode) {
+                            const float wf = fv * w16[e];
+                            cs[j] += wf;
+                            cq[j] += wf * fv;
+                        } else {
                             cs[j] += fv;
                             cq[j] += fv * fv;
                         }
                     }
-        } else
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const T sv = from_f<T>(acc[i][j][e] + bv[j]);
-                *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = sv;
-                if (p.colstats) {      // BatchNorm statistics of the STORED (rounded) values, fused into the producer
-                    const float fv = (m0 + wm * 32 * TM + i * 32 + row < p.M) ? to_f(sv) : 0.f;
-                    cs[j] += fv;
-                    cq[j] += fv * fv;
                 }
-            }
+        }
         // same-wave LDS round trip: no workgroup barrier needed, only the wave's own LDS ops must have landed
         // (WIDE: the block is shared by the WN waves of this wave row -> workgroup barriers around the read-out)
         if constexpr (WIDE) __syncthreads();
@@ -719,8 +754,9 @@ extern "C" {
 static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
                          int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
                          int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
-                         float* colstats, void* stream, const void* addend_mask = nullptr) {
+                         float* colstats, void* stream, const void* addend_mask = nullptr, const unsigned char* rowweight = nullptr) {
     MRFP_CHECK(!addend || aligned16(addend), "conv_fwd: addend must be 16-byte aligned");
+    MRFP_CHECK(!rowweight || (colstats && ((uintptr_t)rowweight & 3) == 0), "conv_fwd_wstats: the row weights need statistics and 4-byte alignment");
     MRFP_CHECK(!addend_mask || (addend && dtype != MRFP_F32 && (N & 7) == 0 && ldy == N),
                "conv_fwd_gated: a gate mask needs an addend, 16-bit activations, N %% 8 == 0 and a dense output");
     MRFP_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && C > 0 && N > 0 && R > 0 && S > 0 && Ho > 0 && Wo > 0,
@@ -734,6 +770,7 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
     ConvP p;
     p.x = (const char*)x; p.w = (const char*)wpack; p.y = (char*)y; p.bias = bias; p.addend = (const char*)addend; p.colstats = colstats;
     p.addend_mask = (const unsigned char*)addend_mask;
+    p.rowweight = rowweight;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.N = (int)N; p.ldy = (int)ldy;
     p.R = (int)R; p.S = (int)S; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
@@ -759,6 +796,7 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
     const int64_t bmax = (int64_t)(kOOB - 1) / img;          // images per launch
     const bool chunked = B > bmax;
     MRFP_CHECK(!chunked || !colstats, "conv_fwd: fused statistics are not available for inputs above 3.75 GB (see mrfp_conv_single_launch)");
+    MRFP_CHECK(!rowweight || !pw_applicable(p, esz), "conv_fwd_wstats: not available on the pointwise kernels");
     if (chunked) p.classed = 0;          // (batch ranges: the class size would change per range)
     int dbg_drop = 0;
     {   // timing-only diagnostics: zero-record descriptors drop that operand's traffic, instruction stream unchanged
@@ -817,6 +855,15 @@ int mrfp_conv_fwd(const void* x, const void* wpack, const float* bias, void* y, 
                          colstats, stream);
 }
 
+int mrfp_conv_fwd_wstats(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
+                         int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
+                         int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, const uint8_t* rowweight, float* colstats,
+                         void* stream) {
+    MRFP_CHECK(rowweight && colstats, "conv_fwd_wstats: row weights and a statistics buffer are required");
+    return conv_fwd_impl(x, wpack, bias, y, dtype, B, H, W, C, N, ldy, R, S, Ho, Wo, stride, pad_h, pad_w, dil, 1, nullptr,
+                         colstats, stream, nullptr, rowweight);
+}
+
 int mrfp_conv_fwd_gated(const void* x, const void* wpack, const float* bias, void* y, int dtype, int64_t B, int64_t H,
                         int64_t W, int64_t C, int64_t N, int64_t ldy, int64_t R, int64_t S, int64_t Ho, int64_t Wo,
                         int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t sstride, const void* addend,
@@ -837,7 +884,7 @@ int64_t mrfp_conv_stats_blocks(int dtype, int64_t B, int64_t H, int64_t W, int64
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
     p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
     p.classed = 0;
-    p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
+    p.bias = nullptr; p.colstats = nullptr; p.rowweight = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
     return stats_row_blocks(p, esz);
 }
 int64_t mrfp_conv_stats_block_rows(int dtype, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t R, int64_t S, int64_t Ho,
@@ -849,7 +896,7 @@ int64_t mrfp_conv_stats_block_rows(int dtype, int64_t B, int64_t H, int64_t W, i
     p.stride = (int)stride; p.pad_h = (int)pad_h; p.pad_w = (int)pad_w; p.dil = (int)dil; p.sstride = (int)sstride;
     p.M = (int)(B * Ho * Wo); p.cpr = (int)(C * esz / 16); p.kchunks = (int)(R * S * p.cpr);
     p.classed = 0;
-    p.bias = nullptr; p.colstats = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
+    p.bias = nullptr; p.colstats = nullptr; p.rowweight = nullptr; p.addend = nullptr; p.addend_mask = nullptr;
     return stats_block_rows(p, esz);
 }
 /* rows the caller must allocate for `colstats` (row blocks + the compacted groups) */

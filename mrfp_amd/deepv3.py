@@ -380,16 +380,23 @@ class MRFPPlus(_DeepLabBase):
                   dict(size=(int(h / 2), int(w / 2))), dict(scale=0.838), dict(scale=0.798),
                   dict(size=(math.ceil(h / 4), math.ceil(w / 4)))]
         t, dec, xp_alias = xp, None, xp
+        from . import conv as conv_mod
         for i, ((conv, bn), rs) in enumerate(zip(self.hrfp_layers(), resize)):
+            if i == 4 and lazy and not need_out:
+                return t, None, xp_alias
+            # (the 3x3 convolutions keep the size: the plan of the resize behind this one is known before it runs, and its epilogue
+            #  sums its output with the resize's pixel multiplicities -- the BatchNorm then has its statistics: conv.STAT_RESIZE)
+            plan = ops.nearest_plan(t.shape[2], t.shape[3], device=t.device, **rs)
+            conv_mod.STAT_RESIZE[0] = plan if bn.training else None
             if i == 0:            # xp also feeds the trunk: the trunk-side gradient rides in this conv's dgrad epilogue
                 t, xp_alias = conv.forward_skip(t)
             elif i == 4:          # OCout_dec also feeds the O2 add: same chaining
-                if lazy and not need_out:
-                    return t, None, xp_alias
                 t, dec = conv.forward_skip(t)
             else:
                 t = conv(t)
-            plan = ops.nearest_plan(t.shape[2], t.shape[3], device=t.device, **rs)
+            conv_mod.STAT_RESIZE[0] = None
+            if (plan.Hs, plan.Ws) != tuple(t.shape[2:]):
+                plan = ops.nearest_plan(t.shape[2], t.shape[3], device=t.device, **rs)
             t = bn.fused(t, relu=True, plan=plan)
             self._tap("hrfp%d" % i, t)
         return dec, t, xp_alias

@@ -110,6 +110,21 @@ class NearestPlan:
         self.tabW = torch.from_numpy(tw).to(device)
         self.invH = torch.from_numpy(_inverse_table(th, Hs)).to(device)
         self.invW = torch.from_numpy(_inverse_table(tw, Ws)).to(device)
+        mh, mw = np.bincount(th, minlength=Hs), np.bincount(tw, minlength=Ws)
+        self._mult = np.outer(mh, mw)          # how many destination pixels read each source pixel
+        self._mult_dev = {}
+
+    def multiplicity(self, B):
+        """uint8 [B*Hs*Ws + 256] on the device (zero padding: mrfp_conv_fwd_wstats reads whole tiles), or None when a pixel
+        is read more than 255 times: the weights with which statistics over the SOURCE equal statistics over the resized tensor."""
+        if B not in self._mult_dev:
+            if self._mult.max() > 255:
+                self._mult_dev[B] = None
+            else:
+                flat = np.zeros(B * self.Hs * self.Ws + 256, dtype=np.uint8)
+                flat[:B * self.Hs * self.Ws] = np.tile(self._mult.astype(np.uint8).reshape(-1), B)
+                self._mult_dev[B] = torch.from_numpy(flat).to(self.tabH.device)
+        return self._mult_dev[B]
 
 
 @lru_cache(maxsize=256)
@@ -266,7 +281,10 @@ class _BatchNormAct(torch.autograd.Function):
         coef = torch.empty(4 * C, dtype=torch.float32, device=dev)
         mean, invstd, A, S = coef[0:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:4 * C]
         if training:
-            fused = getattr(x, "_mrfp_colstats", None) if plan is None else None
+            fused = getattr(x, "_mrfp_colstats", None)
+            # (statistics weighted for a resize -- conv.STAT_RESIZE -- only serve the layer that applies exactly that resize)
+            if fused is not None and (fused[6] if len(fused) > 6 else None) is not plan:
+                fused = None
             if fused is not None and fused[2] == B * Ho * Wo and fused[0].numel() == fused[1] * 2 * C:
                 # the producing convolution already summed its output per channel in its epilogue
                 ws, nb_, nslab = fused[0], 1, fused[1]

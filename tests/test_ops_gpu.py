@@ -294,6 +294,65 @@ def test_instance_norm_relu_pool_is_the_two_operator_sequence(dtype, shape, affi
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 64, 64, 24, 40, 1, dict(scale=1.205)), (2, 64, 128, 33, 47, 2, dict(scale=1.2)),
+                                  (3, 128, 64, 20, 28, 1, dict(scale=0.838)), (2, 128, 256, 16, 48, 2, dict(size=(16, 48))),
+                                  (2, 256, 128, 24, 24, 1, dict(size=(7, 9))), (1, 64, 96, 96, 96, 2, dict(scale=0.798))])
+def test_batch_norm_behind_a_resize_takes_its_statistics_from_the_convolution_epilogue(dtype, case):
+    """HRFP stage conv -> F.interpolate(nearest) -> BatchNorm(train) -> ReLU (reference deepv3.py:320-327): the convolution epilogue
+    sums its output with the resize's pixel multiplicities (mrfp_conv_fwd_wstats), the BatchNorm runs no statistics pass.  Against
+    the two-pass form (same kernels otherwise) and against torch."""
+    o = ops()
+    from mrfp_amd import conv as cv
+    B, C, N, H, W, dil, rs = case
+    x = rnd(B, C, H, W, seed=51)
+    w = rnd(N, C, 3, 3, seed=52, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(N, seed=53, scale=0.1)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    gam, bet = torch.rand(N) + 0.5, torch.randn(N) * 0.1
+    outs = []
+    for fused in (True, False):
+        cv.WSTATS[0] = fused
+        try:
+            xd = dev(x, dtype)
+            wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+            g, be = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
+            rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+            plan = o.nearest_plan(H, W, device=DEV, **rs)
+            hits = cv.WSTATS_HITS[0]
+            cv.STAT_RESIZE[0] = plan
+            c = o.conv2d(xd, wd, bd, 1, dil, dil)
+            assert cv.STAT_RESIZE[0] is None
+            assert cv.WSTATS_HITS[0] == hits + (1 if fused else 0)
+            assert (getattr(c, "_mrfp_colstats", None) is not None) == fused
+            y = o.batch_norm_act(c, g, be, rm, rv, training=True, momentum=0.1, eps=1e-5, relu=True, plan=plan)
+            gy = rnd(*y.shape, seed=54)
+            y.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+            outs.append((y.detach().float(), xd.grad.float(), g.grad, be.grad, rm, rv))
+        finally:
+            cv.WSTATS[0] = True
+    t = tol(dtype)
+    for a, bb in zip(outs[0], outs[1]):       # fused vs two-pass: only the summation order of the statistics differs
+        assert relerr(a, bb) < (2e-5 if dtype == torch.float32 else 2e-2)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    gc, bec = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    cc = F.conv2d(xc, wc, bc, 1, dil, dil)
+    kw = dict(scale_factor=rs["scale"]) if "scale" in rs else dict(size=rs["size"])
+    rmc, rvc = torch.zeros(N), torch.ones(N)
+    yc = F.relu(F.batch_norm(F.interpolate(cc, mode="nearest", **kw), rmc, rvc, gc, bec, True, 0.1, 1e-5))
+    yc.backward(rnd(*yc.shape, seed=54))
+    y, gx, gg, gb, rm, rv = outs[0]
+    assert tuple(y.shape) == tuple(yc.shape)
+    assert relerr(y, yc) < (20 * t if dtype == torch.float32 else 2 * t)
+    assert relerr(rm.cpu(), rmc) < 20 * t and relerr(rv.cpu(), rvc) < 20 * t
+    if dtype == torch.float32:
+        # (relative L2: an output within rounding of 0 may sit on the other side of the ReLU than torch's, and that one gate moves
+        #  a handful of input gradients by percents of the maximum)
+        l2 = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
+        assert l2(gx, xc.grad) < 50 * t and l2(gg, gc.grad) < 50 * t and l2(gb, bec.grad) < 50 * t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_global_avg_pool_add_relu(dtype):
     o = ops()
     x = rnd(2, 256, 7, 9, seed=18)
