@@ -395,27 +395,60 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
         cs[j] = 0.f;
         cq[j] = 0.f;
     }
-    // statistics weights of this lane's rows: four consecutive rows per 32-bit load (the table is padded to whole tiles and 4-byte
-    // aligned, every group of four rows starts at a multiple of 4), kept packed.  `wmode` is uniform: tiles without a table that lie
-    // wholly inside the output (all but the last row tile of every BatchNorm convolution outside the HRFP branch) take the plain
-    // sums -- convert, add, multiply-add per element; the others multiply by the row's weight (0 for rows past M)
+    // `wst` (uniform): the statistics count row m `rowweight[m]` times (ConvP::rowweight).  That variant of the staging loop is a
+    // separate copy: the launches without a table -- every convolution outside the HRFP branch -- run the loop they always ran
+    // (folding both into one loop cost those launches 0.6 %: same-box A/B against the previous library, profiles/r04_experiments.md 13)
     const bool wst = p.colstats && p.rowweight;
-    const bool wmode = p.colstats && (wst || m0 + WM * 32 * TM > p.M);
-    unsigned rwp[M16 ? 2 * TM : 4 * TM];
-#pragma unroll
-    for (int g = 0; g < (M16 ? 2 * TM : 4 * TM); ++g) {
-        const int r0 = M16 ? g * 16 + 4 * lq : (g >> 2) * 32 + 8 * (g & 3) + 4 * lh;
-        rwp[g] = wst ? *reinterpret_cast<const unsigned*>(p.rowweight + (m0 + wm * 32 * TM + r0)) : 0x01010101u;
-    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        if (wst) {
+            // weights of this lane's rows: four consecutive rows per 32-bit load (the table is padded to whole tiles and 4-byte aligned,
+            // every group of four rows starts at a multiple of 4); rows past M weigh 0
+            if constexpr (M16) {
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int rbase = m0 + wm * 32 * TM + i * 32 + i2 * 16 + 4 * lq;
+                    const unsigned pk = *reinterpret_cast<const unsigned*>(p.rowweight + rbase);
+                    float w4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w4[e] = (rbase + e < p.M) ? (float)((pk >> (8 * e)) & 0xffu) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = i2 * 16 + 4 * lq + e;
+                            const T sv = from_f<T>(acc16[2 * i + i2][j][e] + bv[j]);
+                            *reinterpret_cast<T*>(ep + row * EPITCH + (j * 16 + l15) * (int)sizeof(T)) = sv;
+                            const float fv = to_f(sv), wf = fv * w4[e];
+                            cs[j] += wf;
+                            cq[j] += wf * fv;
+                        }
+                }
+            } else {
+                float w16[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rbase = m0 + wm * 32 * TM + i * 32 + 8 * g + 4 * lh;
+                    const unsigned pk = *reinterpret_cast<const unsigned*>(p.rowweight + rbase);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w16[4 * g + e] = (rbase + e < p.M) ? (float)((pk >> (8 * e)) & 0xffu) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const T sv = from_f<T>(acc[i][j][e] + bv[j]);
+                        *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = sv;
+                        const float fv = to_f(sv), wf = fv * w16[e];
+                        cs[j] += wf;
+                        cq[j] += wf * fv;
+                    }
+            }
+        } else
         if constexpr (M16) {
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
-                float w4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    w4[e] = (m0 + wm * 32 * TM + i * 32 + i2 * 16 + 4 * lq + e < p.M) ? (float)((rwp[2 * i + i2] >> (8 * e)) & 0xffu) : 0.f;
+            for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
                 for (int j = 0; j < 2 * TN; ++j)
 #pragma unroll
@@ -424,44 +457,25 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
                         const T sv = from_f<T>(acc16[2 * i + i2][j][e] + bv[j]);
                         *reinterpret_cast<T*>(ep + row * EPITCH + (j * 16 + l15) * (int)sizeof(T)) = sv;
                         if (p.colstats) {
-                            const float fv = to_f(sv);
-                            if (wmode) {
-                                const float wf = fv * w4[e];
-                                cs[j] += wf;
-                                cq[j] += wf * fv;
-                            } else {
-                                cs[j] += fv;
-                                cq[j] += fv * fv;
-                            }
-                        }
-                    }
-            }
-        } else {
-            float w16[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                w16[e] = (m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh < p.M)
-                             ? (float)((rwp[M16 ? 0 : 4 * i + (e >> 2)] >> (8 * (e & 3))) & 0xffu) : 0.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const T sv = from_f<T>(acc[i][j][e] + bv[j]);
-                    *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = sv;
-                    if (p.colstats) {      // BatchNorm statistics of the STORED (rounded) values, fused into the producer
-                        const float fv = to_f(sv);
-                        if (wmode) {
-                            const float wf = fv * w16[e];
-                            cs[j] += wf;
-                            cq[j] += wf * fv;
-                        } else {
+                            const float fv = (m0 + wm * 32 * TM + i * 32 + row < p.M) ? to_f(sv) : 0.f;
                             cs[j] += fv;
                             cq[j] += fv * fv;
                         }
                     }
+        } else
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const T sv = from_f<T>(acc[i][j][e] + bv[j]);
+                *reinterpret_cast<T*>(ep + row * EPITCH + (j * 32 + lr) * (int)sizeof(T)) = sv;
+                if (p.colstats) {      // BatchNorm statistics of the STORED (rounded) values, fused into the producer
+                    const float fv = (m0 + wm * 32 * TM + i * 32 + row < p.M) ? to_f(sv) : 0.f;
+                    cs[j] += fv;
+                    cq[j] += fv * fv;
                 }
-        }
+            }
         // same-wave LDS round trip: no workgroup barrier needed, only the wave's own LDS ops must have landed
         // (WIDE: the block is shared by the WN waves of this wave row -> workgroup barriers around the read-out)
         if constexpr (WIDE) __syncthreads();
