@@ -33,6 +33,24 @@ def test_host_only_entry_points(cdll):
     assert rc != 0 and b"add" in cdll.mrfp_last_error()
 
 
+def test_row_kernels_give_every_workgroup_the_same_number_of_lines(cdll):
+    """mrfp_stats_nslab(B, Ho) = workgroups per image of the statistics / apply / pool kernels (workgroup j walks lines j, j + n, ...):
+    at most the cap (2048 workgroups per launch), never more than the lines, and no workgroup with more than one line above another
+    -- 192 lines over 128 workgroups (two lines for half of them, one for the rest) was 1.5 % of the normalisation family."""
+    cdll.mrfp_stats_nslab.restype = ctypes.c_int64
+    cdll.mrfp_stats_nslab.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    for B in (1, 2, 16, 64):
+        cap = max(1, 2048 // B)
+        for Ho in (1, 5, 48, 96, 127, 128, 129, 192, 231, 256, 277, 321, 332, 384, 768, 1024, 2048, 5000):
+            n = int(cdll.mrfp_stats_nslab(B, Ho))
+            assert 1 <= n <= min(Ho, cap), (B, Ho, n)
+            per = -(-Ho // n)                              # lines of the busiest workgroup
+            assert per == -(-Ho // min(Ho, cap)), (B, Ho, n)      # ... is what the cap forces, not more
+            assert (per - 1) * n < Ho, (B, Ho, n)          # and no workgroup is idle or two lines behind
+            assert n * per - Ho < per or per == 1, (B, Ho, n)
+    assert int(cdll.mrfp_stats_nslab(16, 192)) == 96 and int(cdll.mrfp_stats_nslab(16, 384)) == 128
+
+
 def test_fourier_and_whitening_host_queries(cdll):
     """Host-only queries of the Fourier / whitening families: the band-limited low-band path stores floor(radius)+1
     spectrum columns on planned line lengths and the whole half spectrum otherwise; workspace sizes; argument checks."""
