@@ -149,7 +149,7 @@ static void run(const char* name, const char* d, unsigned long long span, int wp
            bytes / ms * 1e-6 / 256.0, ms);
 }
 
-int main() {
+int main(int argc, char** argv) {
     const unsigned long long total = 1ull << 29;
     char* d = nullptr;
     float* sink = nullptr;
@@ -157,7 +157,8 @@ int main() {
     hipMemset(d, 1, total + (1 << 20));
     hipDeviceSynchronize();
     const unsigned long long spans[] = {8192ull, 16384ull, 1ull << 21, 1ull << 24, total};
-    for (int wpc = 2; wpc <= 3; ++wpc)
+    const int wlo = argc > 1 ? atoi(argv[1]) : 2, whi = argc > 2 ? atoi(argv[2]) : 3;      // workgroups (of 4 waves) per CU
+    for (int wpc = wlo; wpc <= whi; ++wpc)
         for (unsigned long long span : spans) {
             const int iters = span >= (1ull << 29) ? 512 : 2048;
             run<0>("LDS-DMA", d, span, wpc, iters, sink);
@@ -170,7 +171,7 @@ int main() {
             }
         }
     const unsigned strides[] = {128u, 256u, 512u, 640u, 1024u, 1152u, 2048u, 2176u, 4096u, 4224u};
-    for (int wpc = 2; wpc <= 3; ++wpc)
+    for (int wpc = wlo; wpc <= whi; ++wpc)
         for (unsigned st : strides) run_gather(d, st, wpc, 2048, sink);
     return 0;
 }
