@@ -205,14 +205,29 @@ def main():
     if share:
         local = 0
     if use_dist:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # The first multi-GPU run is the driver's, blind: make a failure attributable.  (a) more ranks than
+        # devices is one clear line and a non-zero exit, checked HERE, in the rank (torch.cuda.device_count() does not initialise
+        # the GPU on this image; the launching parent never looks at the devices); (b) the rendezvous and every collective carry an
+        # explicit timeout (MRFP_DIST_TIMEOUT_S, default 120 s) so that a missing rank ends the run with a message instead of the
+        # driver's limit; (c) every rank reports its first step on stderr.
+        ndev = torch.cuda.device_count()
+        if not share and local >= ndev:
+            print("[bench] rank %d (local rank %d of %d): this node exposes only %d GPU(s) to the process -- `--gpus %d` needs %d; "
+                  "nothing was run" % (rank, local, world, ndev, world, world), file=sys.stderr, flush=True)
+            sys.exit(3)
+        tmo = datetime.timedelta(seconds=float(os.environ.get("MRFP_DIST_TIMEOUT_S", "120")))
         torch.cuda.set_device(local)
+        t_init = time.perf_counter()
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        print("[bench] rank %d/%d on cuda:%d: process group (%s) up after %.1f s" % (rank, world, local, backend,
+              time.perf_counter() - t_init), file=sys.stderr, flush=True)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -239,8 +254,12 @@ def main():
     x, y = synth.synth_batch(args.batch, args.size, width, seed=1 + rank)
     x, y = x.to(dev), y.to(dev)
 
-    for _ in range(args.warmup):
+    t_first = time.perf_counter()
+    for i in range(args.warmup):
         trainer.step(x, y)
+        if i == 0 and use_dist:
+            torch.cuda.synchronize()
+            print("[bench] rank %d: first step %.0f ms" % (rank, 1e3 * (time.perf_counter() - t_first)), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

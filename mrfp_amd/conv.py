@@ -159,6 +159,14 @@ def repack_weights(weights, tag="list", biases=None):
     _REPACK_LISTS[tag] = ([weakref.ref(w) for w in weights], [weakref.ref(b) if b is not None else None for b in biases]
                           if biases is not None else None)
     todo, bmap = _repack_selection(weights, biases)
+    # the masters were just rewritten -- possibly through a flat arena they are views of (deepv3._hrfp_arena), which does not bump
+    # the parameters' own version counters: every cached pack of these weights that the batched launch does NOT refresh (another
+    # dtype / padding, a 7x7 filter, a bias mismatch) is marked stale here and rebuilt lazily at its next use
+    sel = {id(pk) for _, pk, _ in todo}
+    for w in weights:
+        for pk in _PACKS.get(id(w), {}).values():
+            if id(pk) not in sel:
+                pk.version = None
     if todo:
         _batched_repack(todo, tag, bmap)
 
@@ -221,8 +229,16 @@ _JOIN_QUEUED = [False]
 def _join_at_end_of_backward():
     _JOIN_QUEUED[0] = False
     flush_wgrads()
+    # what this pass produced is what the next pass OF THE SAME KIND is expected to produce.  Passes are told apart by the
+    # geometry of their first weight gradient (the head's convolution: input shape, batch, dtype and class count are in it), so
+    # two models / two input shapes alternating in one process each keep their own expectation instead of
+    # flushing late or early on the other one's counts.  (Grouping is a speed matter only: every flush is a correct launch.)
+    if _WG_PASS_KEY[0] is not None:
+        if len(_WG_EXPECT_ALL) >= 64 and _WG_PASS_KEY[0] not in _WG_EXPECT_ALL:
+            _WG_EXPECT_ALL.pop(next(iter(_WG_EXPECT_ALL)))
+        _WG_EXPECT_ALL[_WG_PASS_KEY[0]] = dict(_WG_SEEN)
+    _WG_PASS_KEY[0] = None
     _WG_EXPECT.clear()
-    _WG_EXPECT.update(_WG_SEEN)
     _WG_SEEN.clear()
     join_wgrad_stream()
 
@@ -248,14 +264,21 @@ def join_wgrad_stream(stream=None):
 GROUP_WGRAD = [_os.environ.get("MRFP_WGRAD_GROUP", "1") != "0"]
 _WG_QUEUE = {}              # launch geometry -> [(x, dy, sink, weight)]
 _WG_PENDING_BYTES = [0]
-_WG_MAX_BYTES = int(float(_os.environ.get("MRFP_WGRAD_GROUP_GB", "24")) * (1 << 30))    # activations a queue may keep alive
-WGRAD_GROUP_LAUNCHES = []   # sizes of the grouped launches issued (tests / diagnostics; cleared by the reader)
+# Activations (x, dy) the queues may keep alive beyond the point where an immediate launch would have released them.
+# MRFP_WGRAD_GROUP_GB fixes it; by default it is a quarter of the device memory that is free when the first gradient is queued,
+# at most 24 GB (the bench step on a 288 GB part: 24; a large-activation configuration -- configs[4] -- on a fuller device gets
+# less and flushes earlier instead of raising the peak).
+_WG_MAX_BYTES = [int(float(_os.environ["MRFP_WGRAD_GROUP_GB"]) * (1 << 30)) if "MRFP_WGRAD_GROUP_GB" in _os.environ else None]
+import collections as _collections
+WGRAD_GROUP_LAUNCHES = _collections.deque(maxlen=4096)   # sizes of the last grouped launches (tests / diagnostics; bounded)
 _GROUP_MAX = [None]
 # How many problems of a geometry one backward pass produces is learnt from the previous pass: a geometry that came ONCE is
 # launched at once from then on (nothing to group with -- and the last layers of backward, the stem, would otherwise leave as an
 # exposed tail behind the end of the dgrad chain), a repeated one leaves as soon as its expected count is complete.
-_WG_EXPECT = {}             # launch geometry -> problems seen in the last complete backward pass
+_WG_EXPECT = {}             # launch geometry -> problems seen in the last complete backward pass of THIS kind (see _WG_PASS_KEY)
 _WG_SEEN = {}               # ... in the running one
+_WG_PASS_KEY = [None]       # geometry of the first weight gradient of the running backward pass
+_WG_EXPECT_ALL = {}         # pass key -> {launch geometry -> problems} of the last complete pass that started with it
 
 
 _DEBUG_SKIP_WGRAD = _os.environ.get("MRFP_DEBUG_SKIP_WGRAD") == "1"     # timing diagnostics only: weight gradients are NOT computed
@@ -323,6 +346,14 @@ def _queue_wgrad(sig, x, dy, sink, weight):
     if not _JOIN_QUEUED[0]:       # when this backward pass ends: flush every queue, then the caller's stream waits for the side stream
         _JOIN_QUEUED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(_join_at_end_of_backward)
+    if _WG_PASS_KEY[0] is None:   # first weight gradient of this pass: pick up the expectation of the passes that started like it
+        _WG_PASS_KEY[0] = sig
+        _WG_EXPECT.clear()
+        _WG_EXPECT.update(_WG_EXPECT_ALL.get(sig, {}))
+        _WG_SEEN.clear()
+    if _WG_MAX_BYTES[0] is None:
+        free, _total = torch.cuda.mem_get_info(x.device)
+        _WG_MAX_BYTES[0] = min(24 << 30, max(1 << 30, free // 4))
     seen = _WG_SEEN[sig] = _WG_SEEN.get(sig, 0) + 1
     expect = _WG_EXPECT.get(sig, 0)
     if expect == 1 and seen == 1 and sig not in _WG_QUEUE:
@@ -334,20 +365,42 @@ def _queue_wgrad(sig, x, dy, sink, weight):
     _WG_PENDING_BYTES[0] += x.numel() * x.element_size() + dy.numel() * dy.element_size()
     if len(q) >= _GROUP_MAX[0] or (expect > 1 and seen % expect == 0):
         flush_wgrads(sig)
-    elif _WG_PENDING_BYTES[0] > _WG_MAX_BYTES:
+    elif _WG_PENDING_BYTES[0] > _WG_MAX_BYTES[0]:
         flush_wgrads()
 
 
-def _drop_stale_backward_state():
-    """A forward convolution while the end-of-backward callback is still marked as queued: the last backward pass died with an
-    exception before the engine ran its callbacks.  Forget its queued weight gradients (their step is lost anyway) so that the
-    next backward registers its own callback."""
+def _in_backward():
+    """True while the autograd engine is executing a graph task on this thread (a forward convolution issued from inside a
+    backward pass -- activation checkpointing, recomputation in a custom backward -- is legitimate and must not be taken for
+    the sign of a dead pass)."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f is not None and f() != -1
+
+
+def _drop_stale_backward_state(reason="a forward convolution found the end-of-backward callback of an earlier pass still pending"):
+    """The last backward pass died with an exception before the engine ran its callbacks (the harness calls this from the
+    `finally` of its forward/backward, conv2d() when it is called OUTSIDE any backward pass with the callback still marked as
+    queued).  Its queued weight gradients are forgotten -- their step is lost anyway -- so that the next backward registers its
+    own callback; dropping a non-empty queue is reported, never silent."""
+    dropped = sum(len(v) for v in _WG_QUEUE.values())
     _JOIN_QUEUED[0] = False
     _WG_QUEUE.clear()
     _WG_SEEN.clear()
     _WG_EXPECT.clear()
+    _WG_PASS_KEY[0] = None
     _WG_PENDING_BYTES[0] = 0
     GRAD_DEFERRED.clear()
+    if dropped:
+        import warnings
+        warnings.warn("mrfp_amd.conv: %d queued weight gradients of a backward pass that did not finish were dropped (%s)"
+                      % (dropped, reason), RuntimeWarning, stacklevel=3)
+
+
+def backward_failed():
+    """To be called when a backward pass raised (harness.Trainer does, from its `finally`): clears the deferred weight-gradient
+    state at once instead of leaving it for the next forward convolution to find."""
+    if _JOIN_QUEUED[0] or _WG_QUEUE:
+        _drop_stale_backward_state("the backward pass raised")
 
 
 def wgrad_boundary(t):
@@ -637,7 +690,7 @@ def conv2d(x, weight, bias, stride, padding, dilation, phys_out: Optional[int] =
         raise _lib.MrfpHipError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], C))
     Nphys = phys_out if phys_out is not None else _round_up(N, epc)
     _LAST_STATS[0] = None
-    if _JOIN_QUEUED[0]:
+    if _JOIN_QUEUED[0] and not _in_backward():
         _drop_stale_backward_state()
     out = _Conv2d.apply(x, weight, bias, st, ph, pw, dl, Nphys, want_skip)
     y, skip = out if want_skip else (out, None)

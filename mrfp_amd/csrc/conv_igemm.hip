@@ -743,6 +743,16 @@ static int64_t stats_block_rows(const ConvP& p, int esz) {
     return 64;
 }
 
+// tile height (output rows) run_igemm picks for the dgrad of a strided convolution (sstride > 1: neither the pointwise nor the
+// row-reuse kernels take those).  The class-major row order (ConvP::classed) needs every parity class to be WHOLE tiles of it --
+// with MRFP_CONV_T96 / T192 = 2 (A/B runs, tests) the 96- and 192-row tiles reach strided launches too.
+static int strided_tile_rows(const ConvP& p, int esz) {
+    if (p.N <= 64) return 256;
+    if (esz == 2 && use_tile192(p, esz)) return 192;
+    if (use_tile96(p, esz)) return 96;
+    return 128;
+}
+
 template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
@@ -795,6 +805,8 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
         if (on < 0) { const char* e = getenv("MRFP_DGRAD_CLASSED"); on = e ? atoi(e) : 1; }
         p.classed = on && sstride == 2 && stride == 1 && dil == 1 && (Ho & 1) == 0 && (Wo & 1) == 0 && (p.cpr & 7) == 0 &&
                     ((B * (Ho / 2) * (Wo / 2)) % 256) == 0 && !colstats;
+        // ... and whole tiles of the height this launch will actually run (a tile straddling two classes would index past dx)
+        if (p.classed && ((B * (Ho / 2) * (Wo / 2)) % strided_tile_rows(p, esz)) != 0) p.classed = 0;
         // pointwise: rows = the even-even pixels only, the epilogue stores 2 x 2 blocks (measured: three classes of store-only tiles
         // made the class-major form 20 % SLOWER than the per-pixel one on the 1x1 stride-2 downsample dgrads)
         if (p.classed && R == 1 && S == 1 && pad_h == 0 && pad_w == 0) p.classed = 2;

@@ -314,13 +314,20 @@ class Trainer:
         self.graph = False
 
     def _fwd_bwd(self, img, label):
+        from . import conv
         self.opt.zero_grad()
         self.sync.begin()
-        loss = self.model(img, label, training=True)
-        if self.loss_scale != 1.0:
-            loss.backward(torch.full_like(loss, self.loss_scale))
-        else:
-            loss.backward()
+        ok = False
+        try:
+            loss = self.model(img, label, training=True)
+            if self.loss_scale != 1.0:
+                loss.backward(torch.full_like(loss, self.loss_scale))
+            else:
+                loss.backward()
+            ok = True
+        finally:
+            if not ok:          # a pass that raised leaves queued weight gradients and a pending end-of-backward callback behind
+                conv.backward_failed()
         return loss
 
     def step(self, img, label):

@@ -224,6 +224,8 @@ SYNC_BN_CALLS = [0]       # BatchNorm layers that exchanged their statistics acr
 
 _SYNC_BN_GROUP = [None]     # the statistics' own communicator (created once, collectively, at the first synchronised layer)
 _SYNC_BN_COUNTS = {}        # (local element count, world) -> element count over all ranks
+_SYNC_BN_USES = {}          # ... -> how often the key was used (periodic re-validation of the cached count)
+_SYNC_BN_CHECK = int(os.environ.get("MRFP_SYNCBN_CHECK_EVERY", "512"))
 
 
 def _sync_bn_group():
@@ -260,10 +262,19 @@ def _allreduce_stats(ws, rows, C, count, group):
     SYNC_BN_CALLS[0] += 1
     total = 0
     if count:
+        # UNEVEN PER-RANK BATCHES ARE NOT SUPPORTED under SYNC_BN: the cached total is keyed by this rank's count alone, so a rank
+        # whose batch shrinks while this one's does not (a partial last batch of a non-drop_last loader) would leave it stale.
+        # Every MRFP_SYNCBN_CHECK_EVERY-th use of a key (default 512: one host synchronisation per ~5 steps of the bench network)
+        # the all-reduced count is read back again and compared -- a mismatch raises instead of normalising with the wrong N.
         key = (int(count), dist.get_world_size(group))
         total = _SYNC_BN_COUNTS.get(key)
-        if total is None:
-            total = _SYNC_BN_COUNTS[key] = int(round(tot[2 * C].item()))
+        uses = _SYNC_BN_USES[key] = _SYNC_BN_USES.get(key, 0) + 1
+        if total is None or (_SYNC_BN_CHECK > 0 and uses % _SYNC_BN_CHECK == 0):
+            now = int(round(tot[2 * C].item()))
+            if total is not None and now != total:
+                raise _lib.MrfpHipError("SYNC_BN: the element count over all ranks changed from %d to %d while this rank's stayed %d "
+                                        "-- uneven per-rank batches are not supported (use a drop_last loader)" % (total, now, count))
+            total = _SYNC_BN_COUNTS[key] = now
     return torch.stack([hi, lo]).contiguous(), total
 
 

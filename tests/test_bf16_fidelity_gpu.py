@@ -37,7 +37,7 @@ def _learnable_batch(B=4, S=256, seed=3):
     return x.clamp(0, 255).contiguous(), y
 
 
-def _run(dtype, round_weights=False):
+def _run(dtype, round_weights=False, seed=0):
     from mrfp_amd import deepv3
     from mrfp_amd.config import cfg
     from mrfp_amd.deepv3 import InjectedRandom
@@ -48,14 +48,14 @@ def _run(dtype, round_weights=False):
         import io
         with contextlib.redirect_stdout(io.StringIO()):
             m = deepv3.MRFPPlus(19, criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
-        sd = synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=0, residual_gain=0.3)
+        sd = synth.synth_state_dict(synth.spec_of(m.state_dict()), seed=seed, residual_gain=0.3)
         if round_weights:        # the yardstick run: fp32 arithmetic from weights that carry ONE bf16 rounding
             sd = {k: (v.bfloat16().float() if v.is_floating_point() and v.dim() == 4 else v) for k, v in sd.items()}
         m.load_state_dict(sd)
         m = m.to(DEV).train()
-        x, y = _learnable_batch()
+        x, y = _learnable_batch(seed=3 + seed)
         x, y = x.to(DEV), y.to(DEV)
-        noise = {k: v.to(DEV) for k, v in synth.synth_noise(4, seed=4).items()}
+        noise = {k: v.to(DEV) for k, v in synth.synth_noise(4, seed=4 + seed).items()}
         tr = Trainer(m, lr=1e-2)
         # first-step gradients (nothing is updated by _fwd_bwd)
         m.rng = InjectedRandom(TOGGLES[0], noise)

@@ -159,13 +159,16 @@ def test_alternative_tile_variants_in_subprocess():
     code = (
         "import torch, torch.nn.functional as F\n"
         "from mrfp_amd import conv\n"
-        "for (B,Cin,H,W,Cout,k,pad,dil) in [(2,128,240,240,256,3,1,1),(2,304,120,120,256,3,1,1),(3,64,33,31,64,3,1,1),(2,256,48,40,512,1,0,1)]:\n"
+        # (the last two: dgrads of stride-2 convolutions whose parity classes -- 1024 rows -- are whole 128- / 256-row tiles but NOT whole
+        #  96- / 192-row tiles: with those tiles forced the launch must fall back to the per-pixel row order)
+        "for (B,Cin,H,W,Cout,k,pad,dil,st) in [(2,128,240,240,256,3,1,1,1),(2,304,120,120,256,3,1,1,1),(3,64,33,31,64,3,1,1,1),(2,256,48,40,512,1,0,1,1),\n"
+        "                                     (4,128,32,32,128,3,1,1,2),(4,256,32,32,512,1,0,1,2)]:\n"
         "    g = torch.Generator().manual_seed(1)\n"
         "    x = torch.randn(B,Cin,H,W,generator=g).bfloat16().float(); w = (torch.randn(Cout,Cin,k,k,generator=g)*0.05).bfloat16().float()\n"
         "    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)\n"
-        "    yc = F.conv2d(xc, wc, None, 1, pad, dil); gy = torch.randn(yc.shape, generator=g).bfloat16().float(); yc.backward(gy)\n"
+        "    yc = F.conv2d(xc, wc, None, st, pad, dil); gy = torch.randn(yc.shape, generator=g).bfloat16().float(); yc.backward(gy)\n"
         "    xd = x.cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True); wd = w.cuda().requires_grad_(True)\n"
-        "    yd = conv.conv2d(xd, wd, None, 1, pad, dil); yd.backward(gy.cuda().bfloat16().contiguous(memory_format=torch.channels_last))\n"
+        "    yd = conv.conv2d(xd, wd, None, st, pad, dil); yd.backward(gy.cuda().bfloat16().contiguous(memory_format=torch.channels_last))\n"
         "    rel = lambda a, b: ((a.double().cpu()-b.double()).abs().max()/b.double().abs().max()).item()\n"
         "    assert rel(yd, yc) < 1e-2 and rel(xd.grad, xc.grad) < 1e-2 and rel(wd.grad, wc.grad) < 2e-2, (Cin, rel(yd,yc), rel(xd.grad,xc.grad), rel(wd.grad,wc.grad))\n"
         "print('ok')\n")

@@ -392,3 +392,20 @@ def test_deferred_weight_gradient_holds_its_bucket_back(tmp_path):
     assert out["n"] >= 3 and out["held"]
     assert out["after"] == list(range(out["n"]))                         # the notification released every bucket, in index order
     torch.testing.assert_close(out["gw"], out["ref"])
+
+
+def test_more_ranks_than_devices_is_one_clear_line_and_a_nonzero_exit():
+    """a rank whose LOCAL_RANK has no device says so and exits 3 before anything touches a GPU or a
+    rendezvous (the check runs in the RANK, not in the launching parent).  This container has no GPU: every local rank is one
+    too many."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("MRFP_BENCH_SHARE_GPU", None)
+    import torch
+    if torch.cuda.device_count() > 1:
+        pytest.skip("needs a host with fewer than two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-800:])
+    assert "exposes only" in r.stderr and "--gpus 2" in r.stderr and not r.stdout.strip()

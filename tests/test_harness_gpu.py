@@ -330,7 +330,7 @@ def test_grouped_deferred_weight_gradients_equal_the_per_layer_launches():
     try:
         for on in (False, True, True):
             conv.GROUP_WGRAD[0] = on
-            del conv.WGRAD_GROUP_LAUNCHES[:]
+            conv.WGRAD_GROUP_LAUNCHES.clear()
             loss = tr._fwd_bwd(x, y)
             torch.cuda.synchronize()
             assert not conv._WG_QUEUE and not conv.GRAD_DEFERRED
@@ -351,3 +351,111 @@ def test_grouped_deferred_weight_gradients_equal_the_per_layer_launches():
             assert ((a - b).abs().max() / a.abs().max().clamp_min(1e-30)).item() < 2e-5
         else:
             assert torch.equal(a, b)
+
+
+def test_two_trainers_and_two_input_shapes_interleaved_with_grouping_on():
+    """the deferred weight-gradient queues learn how many problems of a geometry a backward pass produces from
+    the previous pass OF THE SAME KIND (conv._WG_EXPECT_ALL, keyed by the pass's first weight-gradient geometry).  Two Trainers
+    (two models) and two input shapes alternating in one process: every pass must reproduce, bit for bit, the gradients the same
+    model / shape gives when it runs alone, leave no queue behind, and -- from its second occurrence on -- issue the same grouped
+    launches as when it runs alone (no late or early flush on the other pass's counts)."""
+    from mrfp_amd import conv
+    from mrfp_amd.deepv3 import InjectedRandom
+    from mrfp_amd.harness import Trainer
+    assert conv.GROUP_WGRAD[0]
+    shapes = [(2, 128, 128), (2, 96, 160)]
+    data = []
+    for i, (b, h, w) in enumerate(shapes):
+        x, y = synth.synth_batch(b, h, w, seed=5 + i)
+        data.append((x.to(DEV), y.to(DEV), {k: v.to(DEV) for k, v in synth.synth_noise(b, seed=7 + i).items()}))
+    trainers = []
+    for _ in range(2):
+        model, _sd = _model()
+        model.train()
+        trainers.append((model, Trainer(model, lr=1e-3)))
+
+    def one(ti, si):
+        model, tr = trainers[ti]
+        x, y, noise = data[si]
+        model.rng = InjectedRandom((True, True, True), noise)
+        conv.WGRAD_GROUP_LAUNCHES.clear()
+        loss = tr._fwd_bwd(x, y)
+        torch.cuda.synchronize()
+        assert not conv._WG_QUEUE and not conv.GRAD_DEFERRED and not conv._JOIN_QUEUED[0]
+        return float(loss), tr.opt.flat_g.clone(), sorted(conv.WGRAD_GROUP_LAUNCHES)
+
+    # alone: each (trainer, shape) twice in a row -- the second pass is the steady state of that kind
+    alone = {}
+    for ti in range(2):
+        for si in range(2):
+            one(ti, si)
+            alone[(ti, si)] = one(ti, si)
+    # interleaved: every switch changes model and / or shape
+    order = [(0, 0), (1, 1), (0, 1), (1, 0), (0, 0), (1, 1), (0, 1), (1, 0)]
+    for ti, si in order:
+        loss, g, groups = one(ti, si)
+        ref = alone[(ti, si)]
+        assert loss == ref[0] and torch.equal(g, ref[1]), (ti, si)
+        assert groups == ref[2], (ti, si, groups, ref[2])       # the expectation of this kind of pass was learnt in the `alone` phase
+    assert len(conv._WG_EXPECT_ALL) <= 64
+
+
+def test_a_backward_pass_that_raises_leaves_no_deferred_state_behind():
+    """a backward that dies must not leave queued weight gradients for the next forward convolution to find (and a
+    forward convolution issued INSIDE a backward pass -- recomputation -- must not be taken for the sign of a dead one)."""
+    import warnings
+    from mrfp_amd import conv
+    from mrfp_amd.deepv3 import InjectedRandom
+    from mrfp_amd.harness import Trainer
+    x, y = synth.synth_batch(2, 128, 128, seed=3)
+    x, y = x.to(DEV), y.to(DEV)
+    noise = {k: v.to(DEV) for k, v in synth.synth_noise(2, seed=4).items()}
+    model, _ = _model()
+    model.train()
+    tr = Trainer(model, lr=1e-3)
+    model.rng = InjectedRandom((True, True, True), noise)
+    loss0 = float(tr._fwd_bwd(x, y))
+    g0 = tr.opt.flat_g.clone()
+
+    class Boom(RuntimeError):
+        pass
+
+    fired = []
+
+    def hook(_g):
+        # a legitimate forward convolution from inside backward (activation recomputation) ...
+        assert conv._in_backward()
+        q = sum(len(v) for v in conv._WG_QUEUE.values())
+        with torch.no_grad():
+            conv.conv2d(torch.zeros(1, 64, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last),
+                        torch.zeros(64, 64, 1, 1, device=DEV), None, 1, 0, 1)
+        assert sum(len(v) for v in conv._WG_QUEUE.values()) == q        # ... did not drop the queues
+        fired.append(q)
+        raise Boom("injected")
+
+    # the hook sits on layer3's input: by then the head, ASPP, layer4 and layer3 have queued their weight gradients
+    h = model.layer3[0].conv1.weight.register_hook(lambda g: g)       # (keeps the parameter's node alive; no-op)
+    handle = []
+    orig = model.layer2.forward
+
+    def fwd(*a, **k):
+        out = orig(*a, **k)
+        t = out[0] if isinstance(out, (list, tuple)) else out
+        handle.append(t.register_hook(hook))
+        return out
+    model.layer2.forward = fwd
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with pytest.raises(Boom):
+                tr._fwd_bwd(x, y)
+        assert fired and not conv._WG_QUEUE and not conv.GRAD_DEFERRED and not conv._JOIN_QUEUED[0]
+        if fired[0]:
+            assert any("queued weight gradients" in str(i.message) for i in w)
+    finally:
+        model.layer2.forward = orig
+        for hd in handle:
+            hd.remove()
+        h.remove()
+    # the next pass is a clean one
+    assert float(tr._fwd_bwd(x, y)) == loss0 and torch.equal(tr.opt.flat_g, g0)
