@@ -240,14 +240,15 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
         // multiples of 4 -- SQ_LDS_BANK_CONFLICT was 5 % of the wave cycles with it).
         const int chunk_a = (t & 7) ^ (rbase & 7);
         auto lds_off_a = [](int row, int ch) { return row * 128 + (((ch ^ row) & 7) << 4); };
-        unsigned r_j = 0, r_okm = 0;   // per piece i: image row j of its patch row (4 bits each) and "inside the image row" bit
+        unsigned long long r_j = 0;    // per piece i: image row j of its patch row (4 bits each: 13 pieces on the 384-row tile)
+        unsigned r_okm = 0;            // ... and its "inside the image row" bit
         unsigned r_base[SAR];   // byte offset of its pixel at filter row r = 1 (the centre row), chunk included
 #pragma unroll
         for (int i = 0; i < SAR; ++i) {
             const int L = rbase + i * RSTEP;
             const int j = L / PWH, x = L - j * PWH - dil, col = ow0 + x;
             const bool ok = j < RT && col >= 0 && col < p.W;
-            r_j |= (unsigned)(j & 15) << (4 * i);
+            r_j |= (unsigned long long)(j & 15) << (4 * i);
             r_okm |= (ok ? 1u : 0u) << i;
             r_base[i] = (unsigned)((b0 * p.H + oh0 + j) * p.W + col) * (unsigned)pixbytes + (unsigned)(chunk_a * 16);
         }
@@ -702,7 +703,7 @@ static int rr_tile(const ConvP& p, int esz) {
         const char* e = getenv("MRFP_CONV_RR");
         g_rr = e ? atoi(e) : 2;
     }
-    if (!g_rr || esz != 2 || p.N <= 64) return 0;
+    if (!g_rr || esz != 2) return 0;
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.sstride != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
     if (p.dil < 1 || p.dil > 2 || p.pad_h != p.dil || p.pad_w != p.dil) return 0;
     if ((p.cpr & 7) != 0 || (p.W & 15) != 0) return 0;
@@ -711,6 +712,20 @@ static int rr_tile(const ConvP& p, int esz) {
         const int PW = p.W < BM ? p.W : BM, RT = BM / PW;
         return RT * (PW + 2 * p.dil) <= BM + 32;
     };
+    if (p.N <= 64) {
+        // N <= 64 (round 5): the HRFP ends (reference deepv3.py:221-237: 128 -> 64, 64 -> 64 at 192^2 .. 384^2) ran on
+        // the plain 256x64 tile at 52 FLOP per fill byte -- 3.3 GB through the fill path for the 64 -> 64 layer at 384^2 = 255 us at
+        // the 13 TB/s that path gives, and 270 us is what the launch takes.  A 384 x 64 tile of four waves STACKED along M (each
+        // 96 x 64: the per-wave tile, fragment reads and MFMA count of the 192x128 row-reuse kernel) fills a patch of 384 + 32 pixel
+        // rows and three 64 x 64 weight tiles per filter row: 77 KB for 3 x 144 MFMAs per wave, 122 FLOP per fill byte.  (Round 2's
+        // 192 x 64 variant -- 53 KB per fill, 82 FLOP per byte, three workgroups per CU -- had measured slower than the plain tile.)
+        // MRFP_CONV_RR64=0 switches it off (A/B runs).
+        static int rr64 = -1;
+        if (rr64 < 0) { const char* e = getenv("MRFP_CONV_RR64"); rr64 = e ? atoi(e) : 1; }
+        if (!rr64 || !fits(384)) return 0;
+        const int64_t t384 = (int64_t)(p.M / 384);
+        return (g_rr >= 3 || t384 >= 512) ? 384 : 0;      // at least one full round at two workgroups per CU
+    }
     // Where it pays (bench.py --dump-convs with the switch off / on, several boxes): long K (C >= 256: at least 12 patch fills
     // per tile to amortise the 76 KB prologue), at least one full round of tiles at two workgroups per CU, and an N that does not
     // waste most of its last 128-column tile.  Lost: M = 36 864, 256 -> 256 (384 tiles: 825 vs 880 TFLOP/s against the 96x128
@@ -726,6 +741,7 @@ static int rr_tile(const ConvP& p, int esz) {
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
 static int64_t stats_row_blocks(const ConvP& p, int esz) {
     if (pw_applicable(p, esz)) return pw_stats_blocks(p);            // pointwise kernels (conv_pw.hip): one per workgroup range
+    if (rr_tile(p, esz) == 384) return (int64_t)(p.M / 384) * 4;      // row-reuse kernel for N <= 64: 384-row tiles, 4 wave rows
     if (rr_tile(p, esz)) return (int64_t)(p.M / 192) * 2;             // row-reuse kernels: 192-row tiles, 2 wave rows
     if (p.N > 64 && use_tile192(p, esz)) return (int64_t)((p.M + 191) / 192) * 2;      // <2,2,3,2>: 192-row tile, 2 wave rows
     if (p.N <= 64) return (int64_t)((p.M + 255) / 256) * 4;          // <4,1,2,2>: 256-row tile, 4 wave rows
@@ -757,7 +773,9 @@ template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (pw_applicable(p, 2)) return pw_run(p, std::is_same<T, f16>::value, st);
-        if (rr_tile(p, 2)) return launch_igemm_rr<T, 2, 2, 3, 2>(p, st);
+        const int rr = rr_tile(p, 2);
+        if (rr == 384) return launch_igemm_rr<T, 4, 1, 3, 2>(p, st);
+        if (rr) return launch_igemm_rr<T, 2, 2, 3, 2>(p, st);
     }
     if (p.N <= 64) return pick_igemm<T, 4, 1, 2, 2>(p, st);
     // (measured and dropped: the 256x256 8-wave tile, a two-wave 96x128 variant, a 256x128 tile, a 160x128 tile:

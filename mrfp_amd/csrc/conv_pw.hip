@@ -40,9 +40,14 @@ struct NoPrev { static constexpr bool value = false; };
 MRFP_STAMP_DECL(g_stamps_pw)
 int stamps_pw(unsigned long long* out, int n) { return MRFP_STAMP_READ(g_stamps_pw, out, n); }
 
-template <typename T, int KB, int NST, bool STATS, bool ADD>
+// HALF (round 5): K = 32 elements -- 64-byte rows of X, ONE k step.  The LDS tile keeps its 128-byte rows (KB = 1); the chunks 4..7
+// of every row are zero-filled by the transfer's bounds check and never read.  (The 32 -> 256 dgrads of the 19-class head at 384^2 /
+// 192^2, reference deepv3.py:214-217 `final2`: 1.2 GB written for 151 MB read -- on the generic unaligned kernel they ran at
+// 3.7 TB/s where tuned MIOpen reaches 5.5: profiles/r05_vs_stock.md.)
+template <typename T, int KB, int NST, bool STATS, bool ADD, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
-    constexpr int ROWB = KB * 128;              // bytes of one row of X (K elements)
+    static_assert(!HALF || KB == 1, "HALF: one 128-byte LDS block per row");
+    constexpr int ROWB = HALF ? 64 : KB * 128;  // bytes of one row of X (K elements)
     constexpr int STAGE = KB * 64 * 128;        // one 64-row tile
     constexpr int NP = KB * 2;                  // DMA pieces (8 rows x 128 B) per wave per tile: KB blocks x 8 pieces / 4 waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,12 +84,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         const int kb = q >> 1, row = (q & 1) * 32 + wave * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ ((row >> 1) & 7);                     // source-side swizzle (LDS image is lane-linear)
         src[q] = (unsigned)row * (unsigned)ROWB + (unsigned)(kb * 128 + ch * 16);
+        if (HALF && ch >= 4) src[q] = kOOB;      // (beyond the 64-byte row: zero fill)
         dst[q] = (unsigned)(kb * 64 * 128 + ((q & 1) * 32 + wave * 8) * 128);
     }
     auto issue = [&](int tile, int slot) {
         const unsigned base = (unsigned)tile * 64u * (unsigned)ROWB;      // rows beyond M lie beyond xbytes: zero fill
 #pragma unroll
-        for (int q = 0; q < NP; ++q) dma16_async(xw, lds0 + (unsigned)(slot * STAGE) + dst[q], base + src[q]);
+        for (int q = 0; q < NP; ++q)
+            dma16_async(xw, lds0 + (unsigned)(slot * STAGE) + dst[q], (HALF && src[q] >= kOOB) ? kOOB : base + src[q]);
     };
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
@@ -98,9 +105,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     // LDS, no 2-byte LDS stores, no epilogue barrier.  Accumulator row r = 4*(lane>>4) + e of channel block j is mapped to
     // channel 8*(r>>2) + 4*j + (r&3) of the wave's 32 columns (a permutation of the weight rows, free at load time): a
     // lane's 2 x 4 values are then channels 8*(lane>>4) .. +7 of its pixel = one 16-byte store.
-    uint4 fw[KB * 2][2];                        // [k step of 32][channel block]
+    constexpr int KSW = HALF ? 1 : KB * 2;      // k steps of 32
+    uint4 fw[KSW][2];                           // [k step of 32][channel block]
 #pragma unroll
-    for (int ks = 0; ks < KB * 2; ++ks)
+    for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + 8 * (l15 >> 2) + 4 * j + (l15 & 3);           // the channel accumulator row l15 of block j stands for
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     // loop body, with `s_waitcnt vmcnt(15) ... vmcnt(0)` spread over the multiplies -- on every iteration, where they drain
     // the transfers of the next tile and the stores of the previous one (seen in the ISA; it cost a third of the kernel).
 #pragma unroll
-    for (int ks = 0; ks < KB * 2; ++ks)
+    for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) settle(fw[ks][j]);
 
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
     auto body = [&](int tile, f32x4 (&acc)[4][2], auto has_prev, const f32x4 (&pacc)[4][2], const uint4 (&pav)[4], const unsigned (&pam)[4]) {
         const int prev = tile - 1;
         const char* a = ring + ((tile - t0) % NST) * STAGE;
-        constexpr int KS = KB * 2;
+        constexpr int KS = KSW;
         // fragment reads run ONE K STEP AHEAD of the multiplies that use them (two register sets): left to itself the compiler
         // issues each pair of reads two MFMAs before their use and waits for them (`s_waitcnt lgkmcnt(1)` after every
         // second MFMA in the ISA), i.e. an LDS latency per 32 cycles of matrix work
@@ -226,7 +234,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
             if constexpr (decltype(has_prev)::value) {
                 // the 4 epilogue quarters of the previous tile, spread over the k steps
                 if constexpr (KS >= 4) { if (ks % (KS / 4) == 0) epilogue_part(prev, ks / (KS / 4), pacc, pav, pam); }
-                else { epilogue_part(prev, 2 * ks, pacc, pav, pam); epilogue_part(prev, 2 * ks + 1, pacc, pav, pam); }
+                else if constexpr (KS == 2) { epilogue_part(prev, 2 * ks, pacc, pav, pam); epilogue_part(prev, 2 * ks + 1, pacc, pav, pam); }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) epilogue_part(prev, i, pacc, pav, pam);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -297,7 +309,9 @@ static bool use_bstat(const ConvP& p, int esz) {
     if (p.Ho != p.H || p.Wo != p.W || p.N < 128 || (p.N & 7) != 0) return false;
     if ((int64_t)p.M * p.ldy * esz >= (int64_t)kOOB) return false;        // the output is addressed through a buffer descriptor
     const int rowb = p.C * esz;
-    return rowb == 128 || rowb == 256 || rowb == 512;
+    static int half = -1;              // MRFP_CONV_PW32=0: K = 32 stays on the generic kernel (A/B runs)
+    if (half < 0) { const char* e = getenv("MRFP_CONV_PW32"); half = e ? atoi(e) : 1; }
+    return rowb == 128 || rowb == 256 || rowb == 512 || (rowb == 64 && half);
 }
 
 // M-tile ranges per panel: two workgroups per CU, each at least 4 tiles long (the weights are loaded once per workgroup),
@@ -312,14 +326,14 @@ static int bstat_chunks(int M, int N) {
     return (tiles + per - 1) / per;              // ranges that actually hold tiles (the trailing ones would be empty)
 }
 
-template <typename T, int KB, bool STATS, bool ADD>
+template <typename T, int KB, bool STATS, bool ADD, bool HALF = false>
 static int launch_bstat(const ConvP& c, hipStream_t st) {
     constexpr int NST = KB == 4 ? 2 : 3;                          // K = 256: 2 x 32 KB stages (two workgroups per CU)
     constexpr int STAGE = KB * 64 * 128;
     const int lds = NST * STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bstat_kernel<T, KB, NST, STATS, ADD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bstat_kernel<T, KB, NST, STATS, ADD, HALF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -336,7 +350,7 @@ static int launch_bstat(const ConvP& c, hipStream_t st) {
         if (dbg < 0) { const char* e = getenv("MRFP_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
         if (dbg & 4) p.ybytes = 0;
     }
-    hipLaunchKernelGGL((conv1x1_bstat_kernel<T, KB, NST, STATS, ADD>), dim3((unsigned)(p.panels * chunks)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv1x1_bstat_kernel<T, KB, NST, STATS, ADD, HALF>), dim3((unsigned)(p.panels * chunks)), dim3(256), lds, st, p);
     MRFP_LAUNCH_CHECK();
     return 0;
 }
@@ -344,6 +358,7 @@ static int launch_bstat(const ConvP& c, hipStream_t st) {
 template <typename T, bool STATS, bool ADD>
 static int run_bstat_v(const ConvP& p, hipStream_t st) {
     const int kb = p.C * 2 / 128;
+    if (kb == 0) return launch_bstat<T, 1, STATS, ADD, true>(p, st);      // K = 32
     return kb == 1 ? launch_bstat<T, 1, STATS, ADD>(p, st) : kb == 2 ? launch_bstat<T, 2, STATS, ADD>(p, st) : launch_bstat<T, 4, STATS, ADD>(p, st);
 }
 template <typename T>

@@ -12,7 +12,7 @@
 // covers whole pixels) and keeps a 4x16 block of the 16x16 product / matrix in registers: 64 FMAs per 16 channels read.
 // Reduction over pixels: registers -> LDS across the pixel slots of the workgroup -> one fp32 partial per workgroup ->
 // fp64 combination in a finalize kernel (fixed order: bitwise reproducible).
-#include "common.hpp"
+#include "conv_common.hpp"      // MFMA wrappers (Mma16), fragment types
 
 namespace mrfp {
 
@@ -99,6 +99,135 @@ __global__ __launch_bounds__(kThreads) void group_moments_kernel(const T* __rest
             float sum = 0.f;
             for (int sl = 0; sl < ppi; ++sl) sum += red[(sl * tpp + t) * 17 + e];
             out[(size_t)t * kPart + (e < 16 ? r * 16 + e : 64 + r)] = sum;
+        }
+    }
+}
+
+// ---- the same moments on the matrix cores (16-bit activations; round 5) ---------------------------------
+// The per-group second moment  M[b,g] = sum_p a_g(p) b_g(p)^T  (reference sync_switchwhiten.py:165, 206-217: bmm over the pixels of a
+// 16-channel group) is a 16 x 16 x (pixels) contraction -- one v_mfma_f32_16x16x32 per group and 32 pixels, the operands taken
+// from memory as they are (bf16 / f16 products are exact in fp32; fp32 accumulation as before).  The VALU kernel above spends 64
+// FMAs per 16 channels read and is bound by their issue (2.0 TB/s bf16, profiles/r01_whitening.md); here the matrix pipe does that
+// work in 16 cycles per KB and the kernel streams.
+//   * a workgroup = 4 waves walks tiles of 32 pixels x one 256-channel slab of its pixel chunk; the tile goes global -> registers
+//     (16-byte loads, one tile ahead) -> LDS rows of 512 + 32 bytes ([pixel][channel]: the memory layout);
+//   * the contraction index (pixel) is the SLOW index of that image, so the MFMA fragments -- lane (channel c = l & 15, pixel
+//     block l >> 4) holds 8 pixels of one channel -- come from the transposing LDS read ds_read_b64_tr_b16 (4 pixel rows x 16
+//     channels per 16-lane group).  Which pixels a lane group takes is free as long as both operands agree: group q reads rows
+//     4q .. 4q+3 and 16+4q .. 16+4q+3, so that the eight rows of a 32-lane half differ mod 8 and the 32-byte row segments fall
+//     into disjoint bank windows at the 544-byte pitch (136 dwords = 8 mod 64);
+//   * a == b (the forward's covariance): ONE fragment serves as both operands;
+//   * the channel sums (sum_p a) are a second MFMA against an all-ones operand (every column of its result is the row sum);
+//   * partials leave in the layout of the VALU kernel ([tpp][68] per workgroup), so the fp64 finalize kernel is shared.
+typedef __attribute__((ext_vector_type(4))) short short4v_w;
+typedef __attribute__((address_space(3))) short4v_w lds_short4v_w;
+constexpr int kMmPitch = 544;          // bytes per pixel row of the LDS tile: 256 channels x 2 B + 32
+constexpr int kMmSlab = 256;           // channels per workgroup
+
+template <typename T> __device__ __forceinline__ uint4 ones_frag();
+template <> __device__ __forceinline__ uint4 ones_frag<bf16>() { return make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); }
+template <> __device__ __forceinline__ uint4 ones_frag<f16>() { return make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u); }
+
+__device__ __forceinline__ uint4 mm_frag(const char* tile, int group_in_slab, int lane) {
+    const int q = lane >> 4, r4 = (lane & 15) >> 2, c4 = lane & 3;
+    const char* p0 = tile + (4 * q + r4) * kMmPitch + group_in_slab * 32 + c4 * 8;
+    const short4v_w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v_w*)(p0));
+    const short4v_w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v_w*)(p0 + 16 * kMmPitch));
+    uint4 r;
+    r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return r;
+}
+
+template <typename T, bool SAME>
+__global__ __launch_bounds__(kThreads, (SAME ? 4 : 3)) void group_moments_mfma_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                                       float* __restrict__ part, int HW, int C, int tpp, int per) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ta = smem;
+    char* const tb = smem + 32 * kMmPitch;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int img = blockIdx.y, chunk = blockIdx.x, slab = blockIdx.z;
+    const int c0 = slab * kMmSlab, cs = min(C - c0, kMmSlab);       // channels of this slab
+    const int ng = cs >> 4;                                          // its groups (<= 16)
+    const int cpp = cs >> 3;                                         // 16-byte chunks per pixel (<= 32)
+    const int nck = 32 * cpp;                                        // chunks per tile (<= 1024)
+    const int p0 = chunk * per, p1 = min(p0 + per, HW);
+    const int ntile = (p1 - p0 + 31) >> 5;
+    const size_t base = (size_t)img * HW * C + c0;
+    uint4 ra[2][4], rb[2][SAME ? 1 : 4];      // two tiles ahead in registers (two named sets: compile-time indices only)
+    int lds_o[4];
+    int px[4], cc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = t + i * kThreads;
+        px[i] = ci < nck ? ci / cpp : -1;
+        cc[i] = ci < nck ? ci - px[i] * cpp : 0;
+        lds_o[i] = px[i] >= 0 ? px[i] * kMmPitch + cc[i] * 16 : 0;
+    }
+    auto load = [&](int tile, uint4 (&qa)[4], uint4 (&qb)[SAME ? 1 : 4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + tile * 32 + px[i];
+            const bool ok = px[i] >= 0 && p < p1;
+            const size_t off = base + (size_t)(ok ? p : p0) * C + cc[i] * 8;
+            const uint4 va = *reinterpret_cast<const uint4*>(a + off);
+            qa[i] = ok ? va : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (!SAME) {
+                const uint4 vb = *reinterpret_cast<const uint4*>(b + off);
+                qb[i] = ok ? vb : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    f32x4 accM[4], accS[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { accM[k][e] = 0.f; accS[k][e] = 0.f; }
+    const uint4 ones = ones_frag<T>();
+    auto step = [&](int tile, uint4 (&qa)[4], uint4 (&qb)[SAME ? 1 : 4]) {
+        __syncthreads();                      // every wave has read the previous tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (px[i] >= 0) {
+                *reinterpret_cast<uint4*>(ta + lds_o[i]) = qa[i];
+                if constexpr (!SAME) *reinterpret_cast<uint4*>(tb + lds_o[i]) = qb[i];
+            }
+        if (tile + 2 < ntile) load(tile + 2, qa, qb);     // two tiles in flight behind this tile's multiplies
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = wave + 4 * k;           // (wave-uniform; the transposing read needs every lane's address: no early exit)
+            const int gs = g < ng ? g : 0;
+            const uint4 fa = mm_frag(ta, gs, lane);
+            uint4 fb = fa;
+            if constexpr (!SAME) fb = mm_frag(tb, gs, lane);
+            Mma16<T>::run(accM[k], fa, fb);
+            Mma16<T>::run(accS[k], fa, ones);
+        }
+    };
+    if (ntile > 0) load(0, ra[0], rb[0]);
+    if (ntile > 1) load(1, ra[1], rb[1]);
+    for (int tile = 0; tile < ntile; tile += 2) {
+        step(tile, ra[0], rb[0]);
+        if (tile + 1 < ntile) step(tile + 1, ra[1], rb[1]);
+    }
+    // D[row = 4 * (lane >> 4) + e][col = lane & 15]: lane (q, j) holds rows 4q .. 4q+3 of column j -- the [4 x 16] block + 4 sums of
+    // thread (g, q) of the VALU kernel
+    float* out = part + ((size_t)img * gridDim.x + chunk) * (size_t)tpp * kPart;
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int g = wave + 4 * k;
+        if (g < ng) {
+            float* o = out + (size_t)(((c0 >> 4) + g) * 4 + q) * kPart;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e * 16 + j] = accM[k][e];
+            if (j == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[64 + e] = accS[k][e];
+            }
         }
     }
 }
@@ -282,6 +411,36 @@ template <typename T>
 static int run_moments(const void* a, const void* b, float* M, float* sum_a, float* ws, int64_t B, int64_t HW, int64_t C,
                        hipStream_t st) {
     const WhitenGeom g = whiten_geom(B, HW, C);
+    static int mfma = -1;              // MRFP_WHITEN_MFMA=0: the VALU kernel for 16-bit activations too (A/B runs)
+    if (mfma < 0) { const char* e = getenv("MRFP_WHITEN_MFMA"); mfma = e ? atoi(e) : 1; }
+    if constexpr (sizeof(T) == 2) {
+        if (mfma) {
+            // ONE round of resident workgroups (4 per CU x 256 CUs; MRFP_WHITEN_WGS) instead of the VALU kernel's ~2 048 short
+            // ones: pixel chunks of whole 32-pixel tiles, never more chunks than the workspace was sized for (g.nch)
+            static int wgs = -1;
+            if (wgs < 0) { const char* e = getenv("MRFP_WHITEN_WGS"); wgs = e ? atoi(e) : 1024; if (wgs < 64) wgs = 1024; }
+            const int slabs = (int)((C + kMmSlab - 1) / kMmSlab);
+            int64_t want = (a == b ? wgs : wgs * 3 / 4) / (B * slabs);      // (a != b: two register sets of two operands, 3 per CU)
+            if (want < 1) want = 1;
+            if (want > g.nch) want = g.nch;
+            int64_t per = (HW + want - 1) / want;
+            per = (per + 31) / 32 * 32;
+            const int nch = (int)((HW + per - 1) / per);
+            const dim3 grid((unsigned)nch, (unsigned)B, (unsigned)slabs);
+            if (a == b)
+                hipLaunchKernelGGL((group_moments_mfma_kernel<T, true>), grid, dim3(kThreads), 32 * kMmPitch, st, (const T*)a, (const T*)b,
+                                   ws, (int)HW, (int)C, g.tpp, (int)per);
+            else
+                hipLaunchKernelGGL((group_moments_mfma_kernel<T, false>), grid, dim3(kThreads), 2 * 32 * kMmPitch, st, (const T*)a,
+                                   (const T*)b, ws, (int)HW, (int)C, g.tpp, (int)per);
+            MRFP_LAUNCH_CHECK();
+            const int nv = g.tpp * kPart;
+            hipLaunchKernelGGL(group_moments_finalize_kernel, dim3((unsigned)((nv + kThreads - 1) / kThreads), (unsigned)B),
+                               dim3(kThreads), 0, st, (const float*)ws, nch, g.tpp, (int)C, M, sum_a);
+            MRFP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((group_moments_kernel<T>), dim3((unsigned)g.nch, (unsigned)B), dim3(kThreads), 0, st, (const T*)a,
                        (const T*)b, ws, (int)HW, (int)C, g.tpp, g.ppi, g.per);
     MRFP_LAUNCH_CHECK();
