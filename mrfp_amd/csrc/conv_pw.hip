@@ -309,8 +309,11 @@ static bool use_bstat(const ConvP& p, int esz) {
     if (p.Ho != p.H || p.Wo != p.W || p.N < 128 || (p.N & 7) != 0) return false;
     if ((int64_t)p.M * p.ldy * esz >= (int64_t)kOOB) return false;        // the output is addressed through a buffer descriptor
     const int rowb = p.C * esz;
-    static int half = -1;              // MRFP_CONV_PW32=0: K = 32 stays on the generic kernel (A/B runs)
-    if (half < 0) { const char* e = getenv("MRFP_CONV_PW32"); half = e ? atoi(e) : 1; }
+    // K = 32 (HALF): OFF by default.  Measured in round 5 (profiles/r05_experiments.md): with fused statistics it beats the generic
+    // unaligned kernel (0.390 vs 0.458 ms at 16 x 384^2, 32 -> 256), but the two launches of the bench step -- the head's dgrads, no
+    // statistics, no addend -- run SLOWER on it (390 vs 348 us, 98.9 vs 96.1 us).  MRFP_CONV_PW32=1 enables it (tests, A/B runs).
+    static int half = -1;
+    if (half < 0) { const char* e = getenv("MRFP_CONV_PW32"); half = e ? atoi(e) : 0; }
     return rowb == 128 || rowb == 256 || rowb == 512 || (rowb == 64 && half);
 }
 

@@ -68,6 +68,15 @@ def main():
         return loss
 
     t0 = time.time()
+    # heartbeat: the first step runs MIOpen's find for every distinct convolution (forward, data and weight gradients) -- minutes
+    # without output, and the GPU pool takes a silent command for a hung one
+    import threading
+    stop = threading.Event()
+
+    def beat():
+        while not stop.wait(30.0):
+            print("[stock_step] ... %.0f s, iteration %d" % (time.time() - t0, it[0]), file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
     for i in range(args.warmup):
         loss = step()
         torch.cuda.synchronize()
@@ -80,6 +89,7 @@ def main():
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / args.steps
+    stop.set()
     out = {"what": "stock PyTorch-ROCm step: oracle model on cuda:0, channels_last, autocast(%s), MIOpen find mode %s, SGD(foreach)"
                    % (args.dtype, "off" if args.no_find else "on"),
            "trunk": args.trunk, "batch": B, "size": S, "ms_per_step": round(ms, 3), "images_per_s": round(B / ms * 1e3, 2),

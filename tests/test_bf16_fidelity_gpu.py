@@ -7,7 +7,8 @@ NP+ noise, once in fp32 and once in bf16 on the HIP path, well-conditioned weigh
 DESIGN.md section 2) -- each compared with a YARDSTICK that says how much deviation the problem itself produces:
   * loss curve / final mIoU: a third run, fp32 arithmetic from initial weights that carry ONE bf16 rounding.  The trajectory at lr 1e-2 is
     chaotic: that run is 4.8 % (mean) / 13.5 % (max) away from the fp32 run point-wise after step 5; the bf16 run 4.1 % / 9.5 %
-    (final losses 0.116 / 0.120 / 0.118, train-batch mIoU 78.1 / 78.8 / 79.3).  Asserted: bf16 within 1.5x the yardstick (floors 3 % / 10 %).
+    (final losses 0.116 / 0.120 / 0.118, train-batch mIoU 78.1 / 78.8 / 79.3).  Asserted (round 5): bf16 within the FIXED maxima of the
+    yardstick's distribution over six seeds (profiles/r05_bf16_yardstick.json, tools/bf16_yardstick_seeds.py): mean 13.2 %, max 31.7 %, 3.7 mIoU points.
   * FIRST-step gradient direction (cosine between the fp32 and the bf16 gradient of final1 / aspp / layer4 / layer3): the CPU oracle
     under torch.autocast(bfloat16) -- stock mixed precision -- against its own fp32 gradient: 0.976 / 0.884 / 0.762 / 0.656; the HIP
     path 0.983 / 0.901 / 0.792 / 0.703 (it rounds activations, not the statistics or the accumulations).  VERDICT r3 proposed >= 0.98:
@@ -132,13 +133,19 @@ def test_bf16_training_tracks_fp32():
     for k in GROUPS:
         assert cos[k] >= cos_stock[k] - 0.03, (k, cos[k], cos_stock[k])
     assert cos["final1"] >= 0.95
-    # the loss curve stays as close to the fp32 one as an fp32 run that starts from weights carrying one bf16 rounding does.  That
-    # yardstick is itself one sample of a chaotic quantity: two builds of this library whose fp32 arithmetic differs only in the
-    # summation order of one backward statistic measured it at mean 0.048 / max 0.135 and mean 0.027 / max 0.082 (the bf16 run: 0.041
-    # and 0.055) -- so the bar is twice the yardstick of the run, and never below the yardstick's own observed range (6 % / 15 %)
-    assert mean(rel[5:]) <= max(0.06, 2.0 * mean(rel_rw[5:])), (mean(rel[5:]), mean(rel_rw[5:]))
-    assert max(rel[5:]) <= max(0.15, 2.0 * max(rel_rw[5:])), (max(rel[5:]), max(rel_rw[5:]))
+    # The loss curve stays as close to the fp32 one as an fp32 run that starts from weights carrying ONE bf16 rounding does.  That
+    # yardstick is a chaotic quantity, so it is NOT taken from this run any more (rounds 3-4 re-based the bar on the same run's sample;
+    # VERDICT r4 item 7d): tools/bf16_yardstick_seeds.py measured it ONCE over six seeds (weights, batch and NP+ noise re-drawn per
+    # seed) -- profiles/r05_bf16_yardstick.json: point-wise deviation of the rounded-weights run after step 5, mean 0.022 .. 0.132,
+    # max 0.081 .. 0.317; |mIoU - mIoU_fp32| up to 0.037; the bf16 run over the same seeds: mean 0.022 .. 0.105, max 0.055 .. 0.224,
+    # mIoU within 0.021 -- and the bars below are the FIXED maxima of that yardstick distribution.  (The rounded-weights run of this
+    # test is still executed and printed as a diagnostic; nothing is asserted against it.)
+    YARD_MEAN, YARD_MAX, YARD_MIOU = 0.132, 0.317, 0.037
+    assert mean(rel[5:]) <= YARD_MEAN, (mean(rel[5:]), mean(rel_rw[5:]))
+    assert max(rel[5:]) <= YARD_MAX, (max(rel[5:]), max(rel_rw[5:]))
     assert abs(l16[-1] - l32[-1]) <= 0.1 * l32[-1]
-    # mIoU on the 0..1 scale against the same yardstick (observed over three builds: |fp32 - rounded-weights| 0.005 .. 0.025, |fp32 - bf16|
-    # 0.001 .. 0.011): twice the run's yardstick, never below its observed range
-    assert abs(m32 - m16) <= max(0.03, 2.0 * abs(m32 - mrw)), (m32, m16, mrw)
+    assert abs(m32 - m16) <= YARD_MIOU, (m32, m16, mrw)
+    # first-step gradient direction, fixed floors from the same six seeds (HIP bf16 vs HIP fp32: final1 0.975 .. 0.989, aspp 0.881 ..
+    # 0.905, layer4 0.746 .. 0.801, layer3 0.663 .. 0.712), 0.03 below the observed minima
+    for k, floor in (("final1", 0.945), ("aspp", 0.85), ("layer4", 0.715), ("layer3", 0.63)):
+        assert cos[k] >= floor, (k, cos[k])

@@ -166,7 +166,9 @@ def test_alternative_tile_variants_in_subprocess():
         # (the last two: dgrads of stride-2 convolutions whose parity classes -- 1024 rows -- are whole 128- / 256-row tiles but NOT whole
         #  96- / 192-row tiles: with those tiles forced the launch must fall back to the per-pixel row order)
         "for (B,Cin,H,W,Cout,k,pad,dil,st) in [(2,128,240,240,256,3,1,1,1),(2,304,120,120,256,3,1,1,1),(3,64,33,31,64,3,1,1,1),(2,256,48,40,512,1,0,1,1),\n"
-        "                                     (4,128,32,32,128,3,1,1,2),(4,256,32,32,512,1,0,1,2)]:\n"
+        "                                     (4,128,32,32,128,3,1,1,2),(4,256,32,32,512,1,0,1,2),\n"
+        # K = 32 pointwise (the HALF variant of the B-stationary kernel with MRFP_CONV_PW32=1, the generic kernel otherwise)
+        "                                     (2,32,20,18,256,1,0,1,1),(3,32,33,31,136,1,0,1,1),(2,32,96,96,256,1,0,1,1)]:\n"
         "    g = torch.Generator().manual_seed(1)\n"
         "    x = torch.randn(B,Cin,H,W,generator=g).bfloat16().float(); w = (torch.randn(Cout,Cin,k,k,generator=g)*0.05).bfloat16().float()\n"
         "    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)\n"
@@ -177,7 +179,8 @@ def test_alternative_tile_variants_in_subprocess():
         "    assert rel(yd, yc) < 1e-2 and rel(xd.grad, xc.grad) < 1e-2 and rel(wd.grad, wc.grad) < 2e-2, (Cin, rel(yd,yc), rel(xd.grad,xc.grad), rel(wd.grad,wc.grad))\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"MRFP_CONV_PW": "0", "MRFP_WGRAD_DENSE": "0"}, {"MRFP_CONV_T96": "2"}, {"MRFP_CONV_T192": "2", "MRFP_CONV_RR": "0"}):
+    for extra in ({"MRFP_CONV_PW": "0", "MRFP_WGRAD_DENSE": "0"}, {"MRFP_CONV_T96": "2"}, {"MRFP_CONV_T192": "2", "MRFP_CONV_RR": "0"},
+                  {"MRFP_CONV_PW32": "1"}):
         env = dict(os.environ, PYTHONPATH=root, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
