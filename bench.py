@@ -387,7 +387,39 @@ def _launch_work(name, d, esz):
                  d["B"] * d.get("Ho", d.get("H", 0)) * d.get("Wo", d.get("W", 0)) * d["C"] if "B" in d else 0)
         passes = sum(1 for k in _TENSOR_ARGS if d.get(k)) + (1.0 / (8 * esz) if d.get("mask") else 0.0)
         return 0.0, esz * elems * passes
-    return 0.0, 0.0
+    try:
+        return 0.0, float(_other_bytes(name, d, esz))
+    except (TypeError, KeyError):          # (an argument name the header spells differently: no byte count, never a failed bench)
+        return 0.0, 0.0
+
+
+def _other_bytes(name, d, esz):
+    """Algorithmic bytes of the launches outside the convolution / normalisation families (`other_ms_per_step` was
+    one number): tensors read + written once, from the launch arguments."""
+    g = d.get
+    if name in ("mrfp_bilinear_fwd", "mrfp_bilinear_fwd_into"):          # read the low-resolution map (+ addend), write the output
+        return esz * g("B") * g("C") * (g("Hi") * g("Wi") + g("Ho") * g("Wo") * (2 if g("addend") else 1))
+    if name in ("mrfp_bilinear_bwd", "mrfp_bilinear_bwd_from"):
+        return esz * g("B") * g("C") * (g("Hi") * g("Wi") + g("Ho") * g("Wo"))
+    if name == "mrfp_upsample_ce_fwd":                                   # low-resolution class scores + int64 labels
+        return esz * g("B") * g("Hi") * g("Wi") * g("ld") + 8 * g("B") * g("H") * g("W")
+    if name == "mrfp_upsample_ce_bwd":
+        return 2 * esz * g("B") * g("Hi") * g("Wi") * g("ld") + 8 * g("B") * g("H") * g("W") + esz * g("B") * g("Hi") * g("Wi") * g("Cd")
+    if name == "mrfp_ce_fwd":
+        return g("npix") * (esz * g("C") + 8)
+    if name == "mrfp_ce_bwd":
+        return g("npix") * (2 * esz * g("C") + 8)
+    if name == "mrfp_sgd_step":                                          # p, g, m read; p, m written
+        return 20 * g("n")
+    if name == "mrfp_pack_weight":                                       # fp32 master read, two packs written
+        return g("N") * g("C") * g("R") * g("S") * 4 + 2 * esz * g("Npad") * g("Cpad") * g("R") * g("S")
+    if name == "mrfp_nchw_to_nhwc_pad":
+        return g("B") * g("H") * g("W") * (4 * g("C") + esz * g("Cpad"))
+    if name in ("mrfp_maxpool_fwd", "mrfp_maxpool_bwd"):
+        return g("B") * g("C") * (esz * g("H") * g("W") + (esz + 1) * ((g("H") + 1) // 2) * ((g("W") + 1) // 2))
+    if name == "mrfp_argmax_hist":
+        return g("npix") * (esz * g("C") + 8 + 1)
+    return 0.0          # (weight packs in one batched launch, philox draws, ...: bytes not derivable from the arguments)
 
 
 def step_roofline(model, trainer, x, y, args):
@@ -400,11 +432,13 @@ def step_roofline(model, trainer, x, y, args):
 
     def hook(name, a):
         fam = _family(name)
-        if fam == "conv" or fam != cur[0] or args.dump_launches:
+        # (the few dozen launches of the "other" family get an event at every change of ENTRY POINT: its breakdown below)
+        key = fam if fam != "other" else "other:" + name
+        if fam == "conv" or key != cur[0] or args.dump_launches:
             e = timer.event()
             timer.record(e, st)
             marks.append([e, fam, []])
-            cur[0] = fam
+            cur[0] = key
         d = dict(zip(_lib.ARG_NAMES[name], a))
         if fam == "conv" and _lib.NOTE[0] is not None and name != "mrfp_conv_wgrad_grouped" and name != "mrfp_conv_wgrad":
             d["Clog"], d["Nlog"] = _lib.NOTE[0]
@@ -423,10 +457,16 @@ def step_roofline(model, trainer, x, y, args):
     peak_f = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # f16 and bf16 MFMA: same dense rate
     fam_ms, fam_bytes, fam_n = {}, {}, {}
     convs = []
+    other = {}
     for i, (e, fam, calls) in enumerate(marks):
         ms = timer.elapsed_ms(e, marks[i + 1][0] if i + 1 < len(marks) else end)
         fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
         fam_n[fam] = fam_n.get(fam, 0) + len(calls)
+        if fam == "other" and calls:
+            o = other.setdefault(calls[0][0], {"launches": 0, "ms": 0.0, "bytes": 0.0})
+            o["launches"] += len(calls)
+            o["ms"] += ms
+            o["bytes"] += sum(_launch_work(n_, d_, esz)[1] for n_, d_ in calls)
         for name, d in calls:
             fl, by = _launch_work(name, d, esz)
             fam_bytes[fam] = fam_bytes.get(fam, 0.0) + by
@@ -497,6 +537,11 @@ def step_roofline(model, trainer, x, y, args):
     if args.fourier:
         roof["fourier"] = hbm_entry("fourier", "fft_rows / fft_cols_mix / dft_rows_inv kernels of mrfp_fourier_mix (3 planes per call)")
     roof["other_ms_per_step"] = round(fam_ms.get("other", 0.0), 3)
+    # ... and what is in it, per entry point (each interval also holds the ATen fills / draws issued between two launches of this library)
+    roof["other"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "bytes": round(v["bytes"]),
+                         "achieved_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["bytes"] > 0 else None,
+                         "bound": "hbm" if v["bytes"] > 0 else "launch"}
+                     for k, v in sorted(other.items(), key=lambda kv: -kv[1]["ms"])}
     return roof
 
 
