@@ -298,4 +298,10 @@ int64_t pw_stats_blocks(const ConvP& p);              // statistics row blocks s
 int64_t pw_stats_block_rows(const ConvP& p);          // output rows one of them covers
 int pw_run(const ConvP& p, bool is_f16, hipStream_t st);
 
+// ---- weight-stationary 3x3 kernel for the 64-input-channel layers (HRFP ends, stem / layer-1 3x3), conv_c64.hip ---------------
+bool c64_applicable(const ConvP& p, int esz);
+int64_t c64_stats_blocks(const ConvP& p);             // statistics rows such a launch writes: [image][sub-strip][slot]
+int64_t c64_stats_block_rows(const ConvP& p);         // NEGATIVE: -(rows per image) -- the rows are per image, not per fixed row count
+int c64_run(const ConvP& p, bool is_f16, hipStream_t st);
+
 }  // namespace mrfp

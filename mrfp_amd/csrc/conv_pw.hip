@@ -35,6 +35,17 @@ struct BsP {
     unsigned xbytes, wbytes, ybytes;
 };
 
+// build-time experiment switches (tools/build_variant.sh; profiles/r05_experiments.md section 8): cache policy of the addend / gate
+// loads and of the output stores (2 = nt), ring depth of the K = 256 instance
+#ifndef MRFP_PW_ADD_AUX
+#define MRFP_PW_ADD_AUX 0
+#endif
+#ifndef MRFP_PW_ST_AUX
+#define MRFP_PW_ST_AUX 0
+#endif
+#ifndef MRFP_PW_NST4
+#define MRFP_PW_NST4 2
+#endif
 struct HasPrev { static constexpr bool value = true; };
 struct NoPrev { static constexpr bool value = false; };
 MRFP_STAMP_DECL(g_stamps_pw)
@@ -152,7 +163,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = tile * 64 + i * 16 + l15;
-                av[i] = bload(ar, (m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB);
+                {
+                    const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(ar, (int)((m < p.M && nl < p.N) ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB), 0, MRFP_PW_ADD_AUX);
+                    av[i] = make_uint4(v_.x, v_.y, v_.z, v_.w);
+                }
                 // the gate bits of these 8 channels (all ones without a mask); a plain tracked load, issued with the addend
                 am[i] = (p.addend_mask && m < p.M && nl < p.N) ? p.addend_mask[((size_t)m * p.ldy + nl) >> 3] : 0xffu;
             }
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bstat_kernel(BsP p) {
         const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB;
         u32x4 dv;
         dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
-        __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)off, 0, MRFP_PW_ST_AUX);
     };
     // multiplies of `tile` into acc; when prev >= 0 the epilogue of tile `prev` (accumulators pacc, addend pav) in between
     auto body = [&](int tile, f32x4 (&acc)[4][2], auto has_prev, const f32x4 (&pacc)[4][2], const uint4 (&pav)[4], const unsigned (&pam)[4]) {
@@ -331,7 +345,7 @@ static int bstat_chunks(int M, int N) {
 
 template <typename T, int KB, bool STATS, bool ADD, bool HALF = false>
 static int launch_bstat(const ConvP& c, hipStream_t st) {
-    constexpr int NST = KB == 4 ? 2 : 3;                          // K = 256: 2 x 32 KB stages (two workgroups per CU)
+    constexpr int NST = KB == 4 ? MRFP_PW_NST4 : 3;               // K = 256: 2 x 32 KB stages (two workgroups per CU)
     constexpr int STAGE = KB * 64 * 128;
     const int lds = NST * STAGE;
     static bool attr_set = false;

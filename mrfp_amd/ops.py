@@ -477,6 +477,11 @@ def _in_plane_sums(x):
     #  0..255 -- and the fp32 parity criteria of the ill-conditioned fixture resolve the SUMMATION ORDER of its statistics:
     #  with the epilogue's sums the stem weight gradient of mrfp_c1 moved 0.37 from fp64 where 3x the reference's own fp32
     #  distance allows 0.19; bf16 storage rounds 10^4 times coarser than that)
+    if (IN_FUSED_STATS[0] and x.element_size() == 2 and fused is not None and len(fused) >= 6 and fused[2] == B * H * W and fused[5] < 0
+            and B * (-fused[5]) == fused[4] and fused[3].numel() >= fused[4] * 2 * C):
+        # the weight-stationary 3x3 kernel (csrc/conv_c64.hip) writes its statistics rows per IMAGE: -fused[5] rows each
+        IN_FUSED_HITS[0] += 1
+        return x, -fused[5], fused[3]
     if (IN_FUSED_STATS[0] and x.element_size() == 2 and fused is not None and len(fused) >= 6 and fused[2] == B * H * W and fused[5] > 0
             and (H * W) % fused[5] == 0 and B * ((H * W) // fused[5]) <= fused[4] and fused[3].numel() >= fused[4] * 2 * C):
         # the producing convolution summed its output per row block in its epilogue, and no row block straddles an image

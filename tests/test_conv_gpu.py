@@ -429,9 +429,64 @@ def test_row_reuse_kernels_in_subprocess():
         "    assert all(torch.equal(ys[0], y) for y in ys[1:]), (B,Cin,H,W,Cout,pad)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="3")
+    env = dict(os.environ, PYTHONPATH=root, MRFP_CONV_RR="3", MRFP_CONV_C64="0")      # (C = 64 would otherwise go to conv_c64.hip)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+C64_CASES = [
+    # (B, H, W, N, dil, bias): one strip / several strips / a ragged last strip, odd sizes of the HRFP chain (231, 277, 321), both
+    # dilation classes with odd H, spans that cross images and strips (B * strips * H not a multiple of 512), N = 64 and 128
+    (2, 20, 18, 64, 1, True), (2, 19, 23, 128, 2, True), (3, 33, 31, 64, 1, False), (1, 96, 384, 64, 1, False),
+    (2, 77, 231, 64, 1, True), (1, 61, 277, 128, 2, True), (2, 45, 321, 64, 2, False), (4, 192, 192, 64, 1, False),
+    (2, 130, 200, 128, 1, False), (16, 48, 48, 128, 2, True),
+]
+
+
+@pytest.mark.parametrize("case", C64_CASES)
+def test_weight_stationary_c64_kernel(case):
+    """csrc/conv_c64.hip (3x3, 64 input channels, N = 64 / 128, dilation 1 / 2: weights in registers, rolling window of image rows)
+    against torch: forward with bias, fused statistics (per image: the InstanceNorm form, and their total), the dgrad form (for N = 64 the
+    dgrad is again a 64 -> 64 launch; with a skip addend), repeated launches bit-identical."""
+    from mrfp_amd import conv, _lib
+    from mrfp_amd._lib import call, ptr, stream
+    B, H, W, N, dil, has_bias = case
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(B, 64, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(N, 64, 3, 3, generator=g) * 0.06).bfloat16().float()
+    b = torch.randn(N, generator=g) * 0.1 if has_bias else None
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yc = F.conv2d(xc, wc, b, 1, dil, dil)
+    gy = torch.randn(yc.shape, generator=g).bfloat16().float()
+    yc.backward(gy)
+    xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV) if has_bias else None
+    assert int(_lib.lib().mrfp_conv_stats_block_rows(_lib.BF16, B, H, W, 64, N, 3, 3, H, W, 1, dil, dil, dil, 1)) < 0      # this kernel
+    yd = conv.conv2d(xd, wd, bd, 1, dil, dil)
+    assert relerr(yd, yc) < 1e-2
+    if not has_bias:        # fused statistics: rows per image, and their total
+        st = yd._mrfp_colstats
+        rows, nblk, rb = st[3], st[4], st[5]
+        assert rb < 0 and B * (-rb) == nblk
+        per = rows[:nblk * 2 * N].view(B, -rb, 2, N).double().sum(1).cpu()
+        yf = yd.detach().double().cpu()
+        assert relerr(per[:, 0], yf.sum((2, 3))) < 1e-4 and relerr(per[:, 1], (yf * yf).sum((2, 3))) < 1e-4
+        tot = st[0].view(st[1], 2, N).double().sum(0).cpu()
+        assert relerr(tot[0], yf.sum((0, 2, 3))) < 1e-4
+    yd.backward(gy.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert relerr(xd.grad, xc.grad) < 1e-2 and relerr(wd.grad, wc.grad) < 2e-2
+    with torch.no_grad():
+        ys = [conv.conv2d(xd.detach(), wd.detach(), bd, 1, dil, dil).clone() for _ in range(3)]
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    if N == 64:             # the addend form (a dgrad with a skip gradient), through the C ABI: y = conv(x) + addend
+        pk = conv.get_pack(wd.detach(), None, torch.bfloat16, 64, 64)
+        add = torch.randn(B, 64, H, W, generator=g).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        out = torch.empty_like(add)
+        call("mrfp_conv_fwd", ptr(xd.detach()), ptr(pk.wf), None, ptr(out), _lib.BF16, B, H, W, 64, 64, 64, 3, 3, H, W, 1, dil, dil, dil, 1,
+             ptr(add), None, stream())
+        ref = F.conv2d(x, w, None, 1, dil, dil) + add.float().cpu()
+        assert relerr(out, ref) < 1e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------
