@@ -23,11 +23,14 @@ namespace mrfp {
 // Fill bytes per output: one 128-byte pixel per 64 / 128 outputs x 576 MACs -- 8 B/clk per CU at full matrix rate, a third of what
 // the path delivers beside compute: the kernel is bound by the matrix pipe / HBM, not by the fill path.
 // Geometry: N = 64: waves = 2 channel groups x 2 pixel sub-strips of 64 (strip of 128 pixels); N = 128: 4 channel groups x 64 pixels.
+// CB = 2 (128 input channels: K = 1 152, the 128 -> 64 / 128 / 256 layers): 288 weight registers per wave, so ONE wave per SIMD
+// (512 registers) and one workgroup per CU; a window pixel is two 128-byte halves kept as two [pixel][128 B] planes (each with the
+// conflict-free swizzle of the 64-channel window); N = 256 runs as two column groups of 128 (grid.y).
 // =============================================================================================
 
 struct C64P {
-    const char* x;       // [B][H][W][64] 16-bit
-    const char* w;       // forward-form pack [N][3][3][64]
+    const char* x;       // [B][H][W][C] 16-bit, C = 64 * CB
+    const char* w;       // forward-form pack [N][3][3][C]
     char* y;             // [B][H][W][ldy]
     const float* bias;   // [N] or null
     const char* addend;  // [M][ldy] or null
@@ -42,20 +45,23 @@ struct C64P {
 
 constexpr int kC64Slots = 4;
 
-template <typename T, int NCG, bool STATS, bool ADD>
-__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64P p) {
+template <typename T, int CB, int NCG, bool STATS, bool ADD>
+__global__ __launch_bounds__(256, (CB == 1 ? 2 : 1)) void conv3x3_c64_kernel(C64P p) {
     constexpr int PSN = 4 / NCG;                 // pixel sub-strips per workgroup
     constexpr int SW = 64 * PSN;                 // strip width
-    constexpr int NPIECE = (SW + 4 + 7) / 8;     // 8-pixel DMA pieces per window row (dilation <= 2: 2 halo pixels either side)
-    constexpr int PWV = (NPIECE + 3) / 4;        // pieces issued per wave and row (the surplus ones land in a dump piece)
-    constexpr int SLOT = NPIECE * 1024;
+    constexpr int NPIECE = (SW + 4 + 7) / 8;     // 8-pixel DMA pieces per window row and 64-channel half (dilation <= 2: 2 halo pixels either side)
+    constexpr int NPC = CB * NPIECE;             // pieces per window row
+    constexpr int PWV = (NPC + 3) / 4;           // pieces issued per wave and row (the surplus ones land in a dump piece)
+    constexpr int SLOT = NPC * 1024;
+    constexpr int KS = 18 * CB;                  // k steps of 32 channels: (filter row, tap, half, step)
+    constexpr int PIXB = 128 * CB;               // bytes per pixel of x
     constexpr int ST = 4;                        // output stores per wave and row (unconditional: counted by vmcnt)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int cg = wave % NCG, ps = wave / NCG;
-    const int n0 = cg * 32, nl = n0 + 8 * lq;
+    const int n0 = (int)blockIdx.y * 128 + cg * 32, nl = n0 + 8 * lq;
     const int d = p.dil;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned dump = lds0 + kC64Slots * SLOT;
@@ -65,16 +71,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64P p) {
     const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend ? p.addend : p.y), 0, (int)p.ybytes, 0x00020000);
 
     // ---- weights: this wave's 32 channels x 576, as MFMA A fragments (row l15 of block j = channel n0 + 8*(l15>>2) + 4*j + (l15&3)) ----
-    uint4 fw[18][2];
+    uint4 fw[KS][2];      // (the pack is [N][tap][C]: k step ks = ((tap * CB + half) * 2 + step) is 64 contiguous bytes at ks * 64)
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + 8 * (l15 >> 2) + 4 * j + (l15 & 3);
-            fw[ks][j] = bload(wr, n < p.N ? (unsigned)n * 1152u + (unsigned)(ks * 64 + lq * 16) : kOOB);
+            fw[ks][j] = bload(wr, n < p.N ? (unsigned)n * (unsigned)(1152 * CB) + (unsigned)(ks * 64 + lq * 16) : kOOB);
         }
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) settle(fw[ks][j]);
     float bv[2][4];
@@ -155,22 +161,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64P p) {
                 cur_b = b;
             }
         }
-        const unsigned imgbase = (unsigned)b * (unsigned)p.H * (unsigned)p.W * 128u;
+        const unsigned imgbase = (unsigned)b * (unsigned)p.H * (unsigned)p.W * (unsigned)PIXB;
         const int col0 = ow0 - d + (lane >> 3);   // image column of this lane's pixel in piece 0
         auto issue_row = [&](int i) {            // class row i -> image row q + d * i, into slot (i + 4) & 3
             const int ih = q + d * i;
             const bool rok = i >= 0 && ih < p.H;
-            const unsigned rbase = imgbase + (unsigned)(rok ? ih : 0) * (unsigned)p.W * 128u;
+            const unsigned rbase = imgbase + (unsigned)(rok ? ih : 0) * (unsigned)p.W * (unsigned)PIXB;
             const unsigned sbase = lds0 + (unsigned)(((i + 4) & 3) * SLOT);
 #pragma unroll
             for (int j = 0; j < PWV; ++j) {
                 const int pi = j * 4 + wave;          // (wave-uniform: the transfer's LDS address is a scalar)
+                const int hf = pi / NPIECE, pp = pi - hf * NPIECE;      // 64-channel half, 8-pixel piece inside it
                 // (the column offsets are recomputed per row -- a dozen vector instructions -- rather than held in registers across
-                //  the 144 multiplies of a row: the weights take 144 of the 256 registers)
-                const int col = col0 + 8 * pi, px = 8 * pi + (lane >> 3);
-                const bool cok = pi < NPIECE && col >= 0 && col < p.W;
-                const unsigned cb = (unsigned)(col * 128 + (((lane & 7) ^ (px & 7)) << 4));
-                dma16_async(xw, pi < NPIECE ? sbase + (unsigned)(pi * 1024) : dump, (rok && cok) ? rbase + cb : kOOB);
+                //  the multiplies of a row: the weights take 144 of the 256 registers)
+                const int col = col0 + 8 * pp, px = 8 * pp + (lane >> 3);
+                const bool cok = pi < NPC && col >= 0 && col < p.W;
+                const unsigned cb = (unsigned)(col * PIXB + hf * 128 + (((lane & 7) ^ (px & 7)) << 4));
+                dma16_async(xw, pi < NPC ? sbase + (unsigned)(pi * 1024) : dump, (rok && cok) ? rbase + cb : kOOB);
             }
         };
         // warm-up: the window rows of the first output row
@@ -204,15 +211,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64P p) {
                                     lds0 + (unsigned)(((i + 1) & 3) * SLOT)};
             uint4 fx[2][4];
             auto read_x = [&](int ks, uint4 (&f)[4]) {
-                const int r = ks / 6, s = (ks >> 1) % 3, kk = ks & 1;
-                const char* base = smem + (sb[r] - lds0) + foff[s][kk];
+                const int r = ks / (6 * CB), s = (ks / (2 * CB)) % 3, hf = (ks >> 1) % CB, kk = ks & 1;
+                const char* base = smem + (sb[r] - lds0) + hf * (NPIECE * 1024) + foff[s][kk];
 #pragma unroll
                 for (int bk = 0; bk < 4; ++bk) f[bk] = *reinterpret_cast<const uint4*>(base + bk * 2048);
             };
             read_x(0, fx[0]);
 #pragma unroll
-            for (int ks = 0; ks < 18; ++ks) {
-                if (ks + 1 < 18) read_x(ks + 1, fx[(ks + 1) & 1]);
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) read_x(ks + 1, fx[(ks + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int bk = 0; bk < 4; ++bk)
@@ -286,7 +293,17 @@ bool c64_applicable(const ConvP& p, int esz) {
     if (!g_c64 || esz != 2) return false;
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.sstride != 1 || p.Ho != p.H || p.Wo != p.W) return false;
     if (p.dil < 1 || p.dil > 2 || p.pad_h != p.dil || p.pad_w != p.dil) return false;
-    if (p.C != 64 || (p.N != 64 && p.N != 128) || (p.ldy & 7) != 0) return false;
+    if ((p.ldy & 7) != 0) return false;
+    if (p.C == 64) { if (p.N != 64 && p.N != 128) return false; }
+    else if (p.C == 128) {        // MRFP_CONV_C128=0: the 128-channel layers stay on the implicit-GEMM tiles (A/B runs)
+        static int c128 = -1;
+        if (c128 < 0) { const char* e = getenv("MRFP_CONV_C128"); c128 = e ? atoi(e) : 1; }
+        if (!c128 || (p.N != 64 && p.N != 128 && p.N != 256)) return false;
+        // one workgroup per CU that first loads 288 registers of weights per wave: it pays from ~32 output row strips per workgroup on
+        // (measured in the step: 128 -> 64 @256^2 188 -> 133 us, @192^2 105 -> 130 us; 128 -> 128 @96^2 52 -> 64 us).  MRFP_CONV_C128=2: always (tests)
+        const int SW = p.N == 64 ? 128 : 64;
+        if (c128 < 2 && (int64_t)p.B * ((p.W + SW - 1) / SW) * p.H < 32 * 256) return false;
+    } else return false;
     if (p.addend_mask || (p.colstats && p.addend)) return false;
     if ((int64_t)p.M * p.ldy * esz >= (int64_t)kOOB || p.H < 2 * p.dil) return false;
     return true;
@@ -294,7 +311,8 @@ bool c64_applicable(const ConvP& p, int esz) {
 static int c64_grid(const ConvP& p) {
     const int SW = p.N == 64 ? 128 : 64;
     const int64_t units = (int64_t)p.B * ((p.W + SW - 1) / SW) * p.H;
-    return (int)(units < 512 ? units : 512);       // two workgroups per CU; every workgroup owns at least one row strip
+    const int64_t cap = p.C == 64 ? 512 : 256;     // two workgroups per CU (64 channels) / one (128: 512 registers per wave)
+    return (int)(units < cap ? units : cap);       // every workgroup owns at least one row strip
 }
 // statistics row slots per image and pixel sub-strip: an upper bound of the workgroups whose span touches one image
 static int c64_spi(const ConvP& p) {
@@ -306,19 +324,25 @@ static int c64_spi(const ConvP& p) {
 int64_t c64_stats_blocks(const ConvP& p) { return (int64_t)p.B * (p.N == 64 ? 2 : 1) * c64_spi(p); }
 int64_t c64_stats_block_rows(const ConvP& p) { return -(int64_t)(p.N == 64 ? 2 : 1) * c64_spi(p); }   // < 0: -(rows per image)
 
-template <typename T, int NCG, bool STATS, bool ADD>
+template <typename T, int CB, int NCG, bool STATS, bool ADD>
 static int c64_launch(const C64P& q, int grid, hipStream_t st) {
     constexpr int SW = 64 * (4 / NCG), NPIECE = (SW + 4 + 7) / 8;
-    const int lds = kC64Slots * NPIECE * 1024 + 1024;
+    const int lds = kC64Slots * CB * NPIECE * 1024 + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<T, NCG, STATS, ADD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<T, CB, NCG, STATS, ADD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_c64_kernel<T, NCG, STATS, ADD>), dim3((unsigned)grid), dim3(256), lds, st, q);
+    hipLaunchKernelGGL((conv3x3_c64_kernel<T, CB, NCG, STATS, ADD>), dim3((unsigned)grid, (unsigned)((q.N + 127) / 128)), dim3(256), lds, st, q);
     MRFP_LAUNCH_CHECK();
     return 0;
+}
+template <typename T, int CB, int NCG>
+static int c64_pick(const ConvP& p, const C64P& q, int grid, hipStream_t st) {
+    if (p.colstats) return c64_launch<T, CB, NCG, true, false>(q, grid, st);
+    if (p.addend) return c64_launch<T, CB, NCG, false, true>(q, grid, st);
+    return c64_launch<T, CB, NCG, false, false>(q, grid, st);
 }
 
 template <typename T>
@@ -332,14 +356,8 @@ static int c64_run_t(const ConvP& p, hipStream_t st) {
     q.spi = c64_spi(p);
     q.xbytes = p.xbytes; q.wbytes = p.wbytes; q.ybytes = (unsigned)((int64_t)p.M * p.ldy * 2);
     const int grid = c64_grid(p);
-    if (p.N == 64) {
-        if (p.colstats) return c64_launch<T, 2, true, false>(q, grid, st);
-        if (p.addend) return c64_launch<T, 2, false, true>(q, grid, st);
-        return c64_launch<T, 2, false, false>(q, grid, st);
-    }
-    if (p.colstats) return c64_launch<T, 4, true, false>(q, grid, st);
-    if (p.addend) return c64_launch<T, 4, false, true>(q, grid, st);
-    return c64_launch<T, 4, false, false>(q, grid, st);
+    if (p.C == 64) return p.N == 64 ? c64_pick<T, 1, 2>(p, q, grid, st) : c64_pick<T, 1, 4>(p, q, grid, st);
+    return p.N == 64 ? c64_pick<T, 2, 2>(p, q, grid, st) : c64_pick<T, 2, 4>(p, q, grid, st);
 }
 int c64_run(const ConvP& p, bool is_f16, hipStream_t st) { return is_f16 ? c64_run_t<f16>(p, st) : c64_run_t<bf16>(p, st); }
 

@@ -179,8 +179,9 @@ def test_alternative_tile_variants_in_subprocess():
         "    assert rel(yd, yc) < 1e-2 and rel(xd.grad, xc.grad) < 1e-2 and rel(wd.grad, wc.grad) < 2e-2, (Cin, rel(yd,yc), rel(xd.grad,xc.grad), rel(wd.grad,wc.grad))\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"MRFP_CONV_PW": "0", "MRFP_WGRAD_DENSE": "0"}, {"MRFP_CONV_T96": "2"}, {"MRFP_CONV_T192": "2", "MRFP_CONV_RR": "0"},
-                  {"MRFP_CONV_PW32": "1"}):
+    # (MRFP_CONV_C64=0: the 64 / 128-channel 3x3 shapes stay on the implicit-GEMM tiles this test is about)
+    for extra in ({"MRFP_CONV_PW": "0", "MRFP_WGRAD_DENSE": "0"}, {"MRFP_CONV_T96": "2", "MRFP_CONV_C64": "0"},
+                  {"MRFP_CONV_T192": "2", "MRFP_CONV_RR": "0", "MRFP_CONV_C64": "0"}, {"MRFP_CONV_PW32": "1"}):
         env = dict(os.environ, PYTHONPATH=root, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
@@ -435,25 +436,48 @@ def test_row_reuse_kernels_in_subprocess():
 
 
 C64_CASES = [
-    # (B, H, W, N, dil, bias): one strip / several strips / a ragged last strip, odd sizes of the HRFP chain (231, 277, 321), both
-    # dilation classes with odd H, spans that cross images and strips (B * strips * H not a multiple of 512), N = 64 and 128
-    (2, 20, 18, 64, 1, True), (2, 19, 23, 128, 2, True), (3, 33, 31, 64, 1, False), (1, 96, 384, 64, 1, False),
-    (2, 77, 231, 64, 1, True), (1, 61, 277, 128, 2, True), (2, 45, 321, 64, 2, False), (4, 192, 192, 64, 1, False),
-    (2, 130, 200, 128, 1, False), (16, 48, 48, 128, 2, True),
+    # (B, C, H, W, N, dil, bias): one strip / several strips / a ragged last strip, odd sizes of the HRFP chain (231, 277, 321), both
+    # dilation classes with odd H, spans that cross images and strips (B * strips * H not a multiple of the grid), every (C, N) pair
+    (2, 64, 20, 18, 64, 1, True), (2, 64, 19, 23, 128, 2, True), (3, 64, 33, 31, 64, 1, False), (1, 64, 96, 384, 64, 1, False),
+    (2, 64, 77, 231, 64, 1, True), (1, 64, 61, 277, 128, 2, True), (2, 64, 45, 321, 64, 2, False), (4, 64, 192, 192, 64, 1, False),
+    (2, 64, 130, 200, 128, 1, False), (16, 64, 48, 48, 128, 2, True),
+    # 128 input channels, a launch large enough for the default rule (>= 32 row strips per workgroup)
+    (16, 128, 192, 192, 128, 1, False),
+]
+# 128 input channels (one wave per SIMD, two 64-channel halves per window pixel), N = 64 / 128 / 256 (two column groups): small shapes,
+# which the default rule leaves to the implicit-GEMM tiles -- run in a child process with MRFP_CONV_C128=2 (the switch is read once)
+C128_CASES = [
+    (2, 128, 20, 18, 64, 1, True), (2, 128, 19, 23, 128, 2, False), (1, 128, 61, 277, 256, 2, True), (2, 128, 45, 200, 64, 2, False),
+    (3, 128, 96, 96, 128, 1, False), (2, 128, 70, 130, 256, 1, False), (16, 128, 24, 24, 256, 1, True),
 ]
 
 
 @pytest.mark.parametrize("case", C64_CASES)
 def test_weight_stationary_c64_kernel(case):
-    """csrc/conv_c64.hip (3x3, 64 input channels, N = 64 / 128, dilation 1 / 2: weights in registers, rolling window of image rows)
-    against torch: forward with bias, fused statistics (per image: the InstanceNorm form, and their total), the dgrad form (for N = 64 the
-    dgrad is again a 64 -> 64 launch; with a skip addend), repeated launches bit-identical."""
+    """csrc/conv_c64.hip (3x3, 64 / 128 input channels, dilation 1 / 2: weights in registers, rolling window of image rows) against torch:
+    forward with bias, fused statistics (per image: the InstanceNorm form, and their total), the dgrad form, the addend form (a dgrad
+    with a skip gradient), repeated launches bit-identical."""
+    _c64_check(case)
+
+
+def test_weight_stationary_kernel_128_channels_small_shapes_in_subprocess():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import test_conv_gpu as t\nfor c in t.C128_CASES:\n    t._c64_check(c)\nprint('ok')\n"
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.path.join(root, "tests"), MRFP_CONV_C128="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def _c64_check(case):
     from mrfp_amd import conv, _lib
     from mrfp_amd._lib import call, ptr, stream
-    B, H, W, N, dil, has_bias = case
-    g = torch.Generator().manual_seed(H * 7 + W)
-    x = torch.randn(B, 64, H, W, generator=g).bfloat16().float()
-    w = (torch.randn(N, 64, 3, 3, generator=g) * 0.06).bfloat16().float()
+    B, C, H, W, N, dil, has_bias = case
+    g = torch.Generator().manual_seed(H * 7 + W + C)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(N, C, 3, 3, generator=g) * (0.06 if C == 64 else 0.04)).bfloat16().float()
     b = torch.randn(N, generator=g) * 0.1 if has_bias else None
     xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     yc = F.conv2d(xc, wc, b, 1, dil, dil)
@@ -462,7 +486,7 @@ def test_weight_stationary_c64_kernel(case):
     xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     wd = w.to(DEV).requires_grad_(True)
     bd = b.to(DEV) if has_bias else None
-    assert int(_lib.lib().mrfp_conv_stats_block_rows(_lib.BF16, B, H, W, 64, N, 3, 3, H, W, 1, dil, dil, dil, 1)) < 0      # this kernel
+    assert int(_lib.lib().mrfp_conv_stats_block_rows(_lib.BF16, B, H, W, C, N, 3, 3, H, W, 1, dil, dil, dil, 1)) < 0      # this kernel
     yd = conv.conv2d(xd, wd, bd, 1, dil, dil)
     assert relerr(yd, yc) < 1e-2
     if not has_bias:        # fused statistics: rows per image, and their total
@@ -479,14 +503,14 @@ def test_weight_stationary_c64_kernel(case):
     with torch.no_grad():
         ys = [conv.conv2d(xd.detach(), wd.detach(), bd, 1, dil, dil).clone() for _ in range(3)]
     assert all(torch.equal(ys[0], y) for y in ys[1:])
-    if N == 64:             # the addend form (a dgrad with a skip gradient), through the C ABI: y = conv(x) + addend
-        pk = conv.get_pack(wd.detach(), None, torch.bfloat16, 64, 64)
-        add = torch.randn(B, 64, H, W, generator=g).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        out = torch.empty_like(add)
-        call("mrfp_conv_fwd", ptr(xd.detach()), ptr(pk.wf), None, ptr(out), _lib.BF16, B, H, W, 64, 64, 64, 3, 3, H, W, 1, dil, dil, dil, 1,
-             ptr(add), None, stream())
-        ref = F.conv2d(x, w, None, 1, dil, dil) + add.float().cpu()
-        assert relerr(out, ref) < 1e-2
+    # the addend form (a dgrad with a skip gradient), through the C ABI: y = conv(x) + addend
+    pk = conv.get_pack(wd.detach(), None, torch.bfloat16, C, N)
+    add = torch.randn(B, N, H, W, generator=g).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = torch.empty_like(add)
+    call("mrfp_conv_fwd", ptr(xd.detach()), ptr(pk.wf), None, ptr(out), _lib.BF16, B, H, W, C, N, N, 3, 3, H, W, 1, dil, dil, dil, 1,
+         ptr(add), None, stream())
+    ref = F.conv2d(x, w, None, 1, dil, dil) + add.float().cpu()
+    assert relerr(out, ref) < 1e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@
 # (the GPU box has no .git): `gpurun -- "MRFP_COMMIT=$(git rev-parse --short HEAD) bash tools/measure_traffic.sh"`.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${MRFP_ROUND:-r04}; export MRFP_ROUND=$TAG
+TAG=${MRFP_ROUND:-r05}; export MRFP_ROUND=$TAG
 O=$R/gpurun_out/traffic_$TAG
 rm -rf $O && mkdir -p $O
 STEPS=3; WARM=2
