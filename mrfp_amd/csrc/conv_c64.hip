@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, (CB == 1 ? 2 : 1)) void conv3x3_c64_kernel(C64
     constexpr int SW = 64 * PSN;                 // strip width
     constexpr int NPIECE = (SW + 4 + 7) / 8;     // 8-pixel DMA pieces per window row and 64-channel half (dilation <= 2: 2 halo pixels either side)
     constexpr int NPC = CB * NPIECE;             // pieces per window row
-    constexpr int PWV = (NPC + 3) / 4;           // pieces issued per wave and row (the surplus ones land in a dump piece)
+    constexpr int PWV = (NPC + 3) / 4;           // rounds of piece issue per row (wave w takes pieces w, w + 4, ...)
     constexpr int SLOT = NPC * 1024;
     constexpr int KS = 18 * CB;                  // k steps of 32 channels: (filter row, tap, half, step)
     constexpr int PIXB = 128 * CB;               // bytes per pixel of x
@@ -64,7 +64,6 @@ __global__ __launch_bounds__(256, (CB == 1 ? 2 : 1)) void conv3x3_c64_kernel(C64
     const int n0 = (int)blockIdx.y * 128 + cg * 32, nl = n0 + 8 * lq;
     const int d = p.dil;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned dump = lds0 + kC64Slots * SLOT;
     const i32x4 xw = rsrc_words(p.x, p.xbytes);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.ybytes, 0x00020000);
@@ -171,13 +170,16 @@ __global__ __launch_bounds__(256, (CB == 1 ? 2 : 1)) void conv3x3_c64_kernel(C64
 #pragma unroll
             for (int j = 0; j < PWV; ++j) {
                 const int pi = j * 4 + wave;          // (wave-uniform: the transfer's LDS address is a scalar)
+                // (a wave without a piece in this round issues nothing: the counted wait below leaves only the output STORES
+                //  outstanding, so the number of transfers per wave need not be uniform)
+                if (pi >= NPC) continue;
                 const int hf = pi / NPIECE, pp = pi - hf * NPIECE;      // 64-channel half, 8-pixel piece inside it
                 // (the column offsets are recomputed per row -- a dozen vector instructions -- rather than held in registers across
                 //  the multiplies of a row: the weights take 144 of the 256 registers)
                 const int col = col0 + 8 * pp, px = 8 * pp + (lane >> 3);
-                const bool cok = pi < NPC && col >= 0 && col < p.W;
+                const bool cok = col >= 0 && col < p.W;
                 const unsigned cb = (unsigned)(col * PIXB + hf * 128 + (((lane & 7) ^ (px & 7)) << 4));
-                dma16_async(xw, pi < NPC ? sbase + (unsigned)(pi * 1024) : dump, (rok && cok) ? rbase + cb : kOOB);
+                dma16_async(xw, sbase + (unsigned)(pi * 1024), (rok && cok) ? rbase + cb : kOOB);
             }
         };
         // warm-up: the window rows of the first output row

@@ -106,6 +106,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
 
     // tap tracking: scalar (r, s, tile-in-tap) when ALIGNED, per-thread (r, s, chunk-in-tap) otherwise
     // (CLASSED: the first tap of this tile's class along each axis, every second one after it)
+    // (Round 5 tried skipping, per tile, the filter rows that lie outside the image for every row of the tile -- with a dilation of
+    //  6 / 12 / 18 on a 48-row map a third of the ASPP tiles' K tiles are fills of zeros.  The three launches it helped gained 5 %
+    //  (1 219 -> 1 289 TFLOP/s); the run-time loop bounds cost EVERY instance of this kernel 26 scalar and 4 - 10 vector registers and
+    //  the 192x128 tile 60 bytes of scratch: 332^2 256 -> 128 0.90 -> 1.59 ms, conv family +3.3 ms.  Reverted; profiles/r05_experiments.md 10.)
     const int tr0 = classed ? ((p.pad_h + cph) & 1) : 0, ts0 = classed ? ((p.pad_w + cpw) & 1) : 0, tstep = classed ? 2 : 1;
     int tr = tr0, ts = ts0, tc = 0;
     if (!ALIGNED) {
