@@ -298,6 +298,12 @@ int64_t pw_stats_blocks(const ConvP& p);              // statistics row blocks s
 int64_t pw_stats_block_rows(const ConvP& p);          // output rows one of them covers
 int pw_run(const ConvP& p, bool is_f16, hipStream_t st);
 
+// ---- weight-stationary kernel for the long-K pointwise layers (K = 512 / 1024 / 1280), conv_pwk.hip -------------------------------
+bool pwk_applicable(const ConvP& p, int esz);
+int64_t pwk_stats_blocks(const ConvP& p);
+int64_t pwk_stats_block_rows(const ConvP& p);
+int pwk_run(const ConvP& p, bool is_f16, hipStream_t st);
+
 // ---- weight-stationary 3x3 kernel for the 64-input-channel layers (HRFP ends, stem / layer-1 3x3), conv_c64.hip ---------------
 bool c64_applicable(const ConvP& p, int esz);
 int64_t c64_stats_blocks(const ConvP& p);             // statistics rows such a launch writes: [image][sub-strip][slot]

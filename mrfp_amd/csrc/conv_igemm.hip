@@ -745,6 +745,7 @@ static int rr_tile(const ConvP& p, int esz) {
 // number of statistics row blocks (= m-tiles x wave rows) the epilogue of a forward launch writes
 static int64_t stats_row_blocks(const ConvP& p, int esz) {
     if (pw_applicable(p, esz)) return pw_stats_blocks(p);            // pointwise kernels (conv_pw.hip): one per workgroup range
+    if (pwk_applicable(p, esz)) return pwk_stats_blocks(p);          // long-K pointwise kernel (conv_pwk.hip): likewise
     if (c64_applicable(p, esz)) return c64_stats_blocks(p);          // weight-stationary 3x3 kernel (conv_c64.hip): one per workgroup and sub-strip
     if (rr_tile(p, esz) == 384) return (int64_t)(p.M / 384) * 4;      // row-reuse kernel for N <= 64: 384-row tiles, 4 wave rows
     if (rr_tile(p, esz)) return (int64_t)(p.M / 192) * 2;             // row-reuse kernels: 192-row tiles, 2 wave rows
@@ -757,6 +758,7 @@ static int64_t stats_row_blocks(const ConvP& p, int esz) {
 // output rows one statistics row block covers (block r = rows [r * rb, (r + 1) * rb) of the [M][N] output)
 static int64_t stats_block_rows(const ConvP& p, int esz) {
     if (pw_applicable(p, esz)) return pw_stats_block_rows(p);
+    if (pwk_applicable(p, esz)) return pwk_stats_block_rows(p);
     if (c64_applicable(p, esz)) return c64_stats_block_rows(p);     // negative: -(statistics rows per image)
     if (rr_tile(p, esz)) return 96;
     if (p.N > 64 && use_tile192(p, esz)) return 96;
@@ -779,6 +781,7 @@ template <typename T>
 static int run_igemm(const ConvP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (pw_applicable(p, 2)) return pw_run(p, std::is_same<T, f16>::value, st);
+        if (pwk_applicable(p, 2)) return pwk_run(p, std::is_same<T, f16>::value, st);
         if (c64_applicable(p, 2)) return c64_run(p, std::is_same<T, f16>::value, st);
         const int rr = rr_tile(p, 2);
         if (rr == 384) return launch_igemm_rr<T, 4, 1, 3, 2>(p, st);

@@ -578,3 +578,59 @@ def test_counted_waits_equal_the_vmcnt0_build(tmp_path):
     assert res[0].keys() == res[1].keys() and len(res[0]) == len(shapes)
     bad = [k for k in res[0] if res[0][k] != res[1][k]]
     assert not bad, bad
+
+
+# (B, C, H, W, N): the long-K pointwise kernel (csrc/conv_pwk.hip: K = 512 / 1024 / 1280, weights in registers, X through an LDS ring)
+PWK_CASES = [
+    (16, 1024, 48, 48, 256),      # the layer-3 reduce convolution / the dgrad of the expand one: 6 tiles per workgroup, two panels
+    (16, 1024, 49, 47, 256),      # ragged M (the last 48-row tile is partial)
+    (11, 512, 70, 70, 136),       # K = 512 (two workgroups per CU), N ends inside a panel
+    (16, 1280, 48, 48, 256),      # bot_aspp: K = 1280 (five K quarters, 320 weight registers)
+    (16, 512, 48, 48, 2048),      # layer-4 expand: sixteen panels
+]
+
+
+@pytest.mark.parametrize("case", PWK_CASES)
+def test_long_k_pointwise_kernel(case):
+    """forward + fused statistics, plain dgrad-form launch, the addend form and the GATED addend form (through the C ABI), repeated
+    launches bit-identical -- against torch."""
+    from mrfp_amd import conv, _lib
+    from mrfp_amd._lib import call, ptr, stream
+    B, C, H, W, N = case
+    g = torch.Generator().manual_seed(C + N + H)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(N, C, 1, 1, generator=g) * (2.0 / C) ** 0.5).bfloat16().float()
+    xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    yd = conv.conv2d(xd, wd, None, 1, 0, 1)
+    yc = F.conv2d(x, w)
+    assert relerr(yd, yc) < 1e-2
+    st = yd._mrfp_colstats
+    tot = st[0].view(st[1], 2, N).double().sum(0).cpu()
+    yf = yd.detach().double().cpu()
+    # (statistics of the fp32 accumulators against sums of the bf16-rounded stored values: zero-mean rounding errors)
+    assert relerr(tot[0], yf.sum((0, 2, 3))) < 5e-3 and relerr(tot[1], (yf * yf).sum((0, 2, 3))) < 1e-3
+    with torch.no_grad():
+        ys = [conv.conv2d(xd.detach(), wd.detach(), None, 1, 0, 1).clone() for _ in range(3)]
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    # addend and gated addend (the dgrad forms), through the C ABI
+    pk = conv.get_pack(wd.detach(), None, torch.bfloat16, C, N)
+    add = torch.randn(B, N, H, W, generator=g).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = torch.empty_like(add)
+    call("mrfp_conv_fwd", ptr(xd.detach()), ptr(pk.wf), None, ptr(out), _lib.BF16, B, H, W, C, N, N, 1, 1, H, W, 1, 0, 0, 1, 1,
+         ptr(add), None, stream())
+    addf = add.float().cpu()
+    assert relerr(out, yc + addf) < 1e-2
+    bits = torch.randint(0, 256, (B * H * W * N // 8,), generator=g, dtype=torch.uint8)
+    keep = ((bits.view(-1, 1) >> torch.arange(8, dtype=torch.uint8)) & 1).bool().view(B, H, W, N).permute(0, 3, 1, 2)
+    out2 = torch.empty_like(add)
+    maskd = bits.to(DEV)
+    call("mrfp_conv_fwd_gated", ptr(xd.detach()), ptr(pk.wf), None, ptr(out2), _lib.BF16, B, H, W, C, N, N, 1, 1, H, W, 1, 0, 0, 1, 1,
+         ptr(add), ptr(maskd), stream())
+    assert relerr(out2, yc + addf * keep) < 1e-2
+    # backward through the operator layer (dgrad + wgrad of this convolution)
+    gy = torch.randn(yc.shape, generator=g).bfloat16().float()
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(xc, wc).backward(gy)
+    yd.backward(gy.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert relerr(xd.grad, xc.grad) < 1e-2 and relerr(wd.grad, wc.grad) < 2e-2
