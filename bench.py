@@ -350,7 +350,7 @@ def _eager_step(trainer, x, y):
 #   * with --fourier: the build-defined Fourier amplitude mix (3 planes per call: x, the partner, y).
 # ---------------------------------------------------------------------------------------------------------------------
 CONV_CALLS = ("mrfp_conv_fwd", "mrfp_conv_fwd_gated", "mrfp_conv_fwd_wstats", "mrfp_conv_wgrad", "mrfp_conv_wgrad_grouped")
-NORM_CALLS = ("mrfp_maxpool_affine_fwd", "mrfp_pool_norm_bwd_stats", "mrfp_pool_norm_bwd_apply", "mrfp_stats_fwd", "mrfp_stats_bwd", "mrfp_stats_bwd_mask", "mrfp_affine_fwd", "mrfp_affine_bwd",
+NORM_CALLS = ("mrfp_maxpool_affine_fwd", "mrfp_pool_norm_bwd_stats", "mrfp_pool_norm_bwd_apply", "mrfp_stats_fwd", "mrfp_stats_bwd", "mrfp_stats_bwd_mask", "mrfp_affine_fwd", "mrfp_affine_fwd_stats", "mrfp_affine_bwd",
               "mrfp_affine_fwd_relu_mask", "mrfp_affine_bwd_mask", "mrfp_bn_finalize", "mrfp_bn_bwd_finalize", "mrfp_in_finalize",
               "mrfp_in_bwd_finalize", "mrfp_np_finalize", "mrfp_np_bwd_finalize", "mrfp_mean_finalize", "mrfp_bn_eval_coef",
               "mrfp_copy_channels")
