@@ -305,6 +305,14 @@ int64_t pwk_stats_block_rows(const ConvP& p);
 int pwk_run(const ConvP& p, bool is_f16, hipStream_t st);
 
 // ---- weight-stationary 3x3 kernel for the 64-input-channel layers (HRFP ends, stem / layer-1 3x3), conv_c64.hip ---------------
+// accumulator-stationary weight gradient of the 3x3 / stride 1 / dilation <= 2 layers (conv_wg3.hip): slab slots per problem it may use
+// (0: never applicable to such a problem), the rule, the launch (slab layout and reduction: conv_wgrad.hip)
+int64_t wg3_splits_bound(int64_t N, int64_t Q, int64_t count);
+bool wg3_applicable(int dtype_size, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho,
+                    int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t dil, int64_t count);
+int wg3_run(const void* const* xs, const void* const* dys, int64_t count, float* slab, bool is_f16, int64_t B, int64_t H, int64_t W, int64_t C,
+            int64_t N, int64_t ldn, int64_t dil, unsigned xbytes, unsigned dybytes, int* splits, hipStream_t st);
+
 bool c64_applicable(const ConvP& p, int esz);
 int64_t c64_stats_blocks(const ConvP& p);             // statistics rows such a launch writes: [image][sub-strip][slot]
 int64_t c64_stats_block_rows(const ConvP& p);         // NEGATIVE: -(rows per image) -- the rows are per image, not per fixed row count

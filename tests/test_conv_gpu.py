@@ -365,6 +365,44 @@ def test_strided_dgrad_class_major_rows_equal_the_per_pixel_form():
         os.remove(f)
 
 
+def test_accumulator_stationary_3x3_wgrad_in_subprocess():
+    """conv_wg3_kernel (csrc/conv_wg3.hip): the weight gradient of the 3x3 / stride 1 / dilation 1-2 layers with dW[64 n][9 taps][64 c] held
+    in the accumulators of a workgroup and the pixels streamed past once (rolling window of image rows + the dY strip), forced wherever
+    it is legal (MRFP_WGRAD3=2; read once per process): all three strip forms (64 x 1 row, 96 x 1, 48 x 2 rows), both dilations, several
+    channel blocks, single and grouped launches, main chunks only and main + remainder workgroups (7 and 22 problems), a channel-padded
+    operand, bf16 and f16 -- against torch's convolution gradient of the same rounded operands, bit-identical between two launches."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import test_conv_gpu as t\n"
+        "for (B,C,H,W,N,dil,n,Ct,dt) in [(2,64,16,64,64,1,1,64,'b'),(1,64,24,128,128,1,1,64,'b'),(2,128,12,96,128,1,3,128,'b'),(2,64,8,48,64,1,1,64,'b'),"
+        "(2,128,16,48,256,2,2,128,'b'),(2,64,20,64,128,2,1,64,'h'),(2,320,12,64,256,1,1,304,'b'),(3,64,40,192,64,1,1,64,'b'),(5,128,40,64,128,1,7,128,'b'),"
+        "(4,256,48,48,256,1,22,256,'b'),(2,128,24,96,64,2,2,128,'h')]:\n"
+        "    g = torch.Generator(device='cuda:0').manual_seed(3)\n"
+        "    dtype = torch.bfloat16 if dt == 'b' else torch.float16\n"
+        "    xs, dys = [], []\n"
+        "    for _ in range(n):\n"
+        "        x = torch.zeros(B,H,W,C,device='cuda:0',dtype=dtype)\n"
+        "        x[..., :Ct] = torch.randn(B,H,W,Ct,device='cuda:0',generator=g).to(dtype)\n"
+        "        xs.append(x.permute(0,3,1,2))\n"
+        "        dys.append((torch.randn(B,H,W,N,device='cuda:0',generator=g) * (0.25 if dt == 'h' else 1.0)).to(dtype).permute(0,3,1,2))\n"
+        "    a = t._wgrad_grouped(xs,dys,N,Ct,3,1,dil,dil) if n > 1 else [t._wgrad_single(xs[0],dys[0],N,Ct,3,1,dil,dil)]\n"
+        "    b = t._wgrad_grouped(xs,dys,N,Ct,3,1,dil,dil) if n > 1 else [t._wgrad_single(xs[0],dys[0],N,Ct,3,1,dil,dil)]\n"
+        "    for i in range(n):\n"
+        "        assert torch.equal(a[i], b[i]) and torch.isfinite(a[i]).all(), (C, N, H, W, i)\n"
+        "        ref = torch.nn.grad.conv2d_weight(xs[i][:, :Ct].float().cpu(), (N,Ct,3,3), dys[i].float().cpu(), 1, dil, dil)\n"
+        "        assert t.relerr(a[i], ref) < 1e-4, (C, N, H, W, dil, i, t.relerr(a[i], ref))\n"
+        "print('ok')\n") % os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"MRFP_WGRAD3": "2"}, {"MRFP_WGRAD3": "0"}):
+        env = dict(os.environ, PYTHONPATH=root, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_wgrad_256x128_tile_in_subprocess():
     """conv_wgrad_kernel<..., TMB = 4>: the 256 x 128 weight-gradient tile (16-bit LDS-DMA kernels, N % 256 == 0) forced wherever
     it is legal (MRFP_WGRAD_BIG=2; the switch is read once per process) -- single and grouped launches, dense (pointwise) and
