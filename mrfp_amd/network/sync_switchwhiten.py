@@ -18,6 +18,10 @@ from torch.nn.parameter import Parameter
 from .. import ops
 
 
+def _world_size() -> int:
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 class _AllReduceMean(torch.autograd.Function):
     """all_reduce(sum)/world in forward and in backward -- SyncMeanCov of reference sync_switchwhiten.py:20-26, 44-45."""
 
@@ -92,7 +96,13 @@ class SyncSwitchWhiten2d(nn.Module):
                 wm, shift = self._transform(s / hw, M, sq, N, C, hw)
                 return wm, shift
             params = [p for p in (self.sw_mean_weight, self.sw_var_weight, self.weight, self.bias) if p is not None]
-            return ops.group_whiten(x, algebra, params)
+            # training, one process: the ~200 launches of the algebra replay as two captured hipGraphs (ops._AlgebraGraph); with several
+            # ranks the algebra contains the two all-reduces of the batch statistics and stays eager
+            graph = None
+            if self.training and x.is_cuda and torch.is_grad_enabled() and ops.whiten_graph_enabled() and _world_size() == 1:
+                graph = (self, (N, C, H, W, self.sw_type, self.T, self.tie_weight, self.affine, float(self.eps), float(self.momentum)),
+                         (self.running_mean, self.running_cov))
+            return ops.group_whiten(x, algebra, params, graph)
         # other group sizes: plane means + the full C x C Gram on the MFMA "reduce over pixels" GEMM, application as a
         # per-image 1x1 implicit GEMM
         mu = ops.plane_mean(x)                                   # [N, C]

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from functools import lru_cache
 from typing import Optional, Tuple
 
@@ -1277,21 +1278,78 @@ def group_isqrt(cov, T=5):
     return _GroupISqrt.apply(cov, T)
 
 
+class _AlgebraGraph:
+    """The 16x16 algebra between the two activation passes of a whitening layer -- ~100 few-microsecond torch kernels forward, as many
+    backward, launch-bound: 1.4 of the 1.6 ms a SwitchWhiten2d layer takes at 16 x 256 x 96 x 96 -- captured ONCE per (module, shape) as two
+    hipGraphs: the forward algebra over static (s, M) inputs, and torch.autograd.grad of its outputs over static output gradients (the
+    scheme of torch.cuda.make_graphed_callables, written out because the algebra is a closure inside an autograd Function and its
+    running-statistics buffers must survive the warm-up runs).  Same kernels in the same order as the eager path: bit-identical results
+    (tests/test_whitening_gpu.py).  A replay overwrites the static tensors the backward graph reads, so a second forward of the same layer
+    before its backward falls back to the eager algebra (`pending`)."""
+
+    def __init__(self, algebra, s, M, params, buffers):
+        self.params = tuple(p for p in params if p.requires_grad)
+        saved = [b.detach().clone() for b in buffers]
+        self.s = s.detach().clone().requires_grad_(True)
+        self.M = M.detach().clone().requires_grad_(True)
+        self.inputs = (self.s, self.M) + self.params
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(3):                       # warm-up: allocator, lazy kernel attributes -- nothing of that may happen in a capture
+                with torch.enable_grad():
+                    Wm, shift = algebra(self.s, self.M)
+                torch.autograd.grad((Wm, shift), self.inputs, (torch.ones_like(Wm), torch.ones_like(shift)), allow_unused=True)
+        cur.wait_stream(side)
+        with torch.no_grad():
+            for b, v in zip(buffers, saved):         # the warm-up runs updated the running statistics three times: undo
+                b.copy_(v)
+        pool = torch.cuda.graph_pool_handle()
+        self.fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd, pool=pool):
+            with torch.enable_grad():
+                self.Wm, self.shift = algebra(self.s, self.M)
+        self.dWm, self.dshift = torch.zeros_like(self.Wm), torch.zeros_like(self.shift)
+        self.bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd, pool=pool):
+            self.grads = torch.autograd.grad((self.Wm, self.shift), self.inputs, (self.dWm, self.dshift), allow_unused=True)
+        self.pending = False
+
+
+_ALG_GRAPHS = weakref.WeakKeyDictionary()      # module -> {(shape, mode, parameter / buffer addresses): _AlgebraGraph}
+
+
+def whiten_graph_enabled():
+    """MRFP_WHITEN_GRAPH=0: the whitening algebra stays eager torch ops (A/B runs, the bit-identity test)."""
+    return os.environ.get("MRFP_WHITEN_GRAPH", "1") != "0"
+
+
 class _GroupWhiten(torch.autograd.Function):
     """moments -> (small algebra, torch autograd) -> apply as ONE node, so that the backward pass touches the activation
     only twice: cross moments of (dy, x), then dx = Wm^T dy + (dM + dM^T) x + ds in a single pass."""
 
     @staticmethod
-    def forward(ctx, x, algebra, *params):
+    def forward(ctx, x, algebra, graph, *params):
         x = _chk(x)
         s, M = _gm_call(x, x)
-        with torch.enable_grad():
-            s_l, M_l = s.requires_grad_(True), M.requires_grad_(True)
-            Wm, shift = algebra(s_l, M_l)
-        Wm_c, shift_c = Wm.detach().float().contiguous(), shift.detach().float().contiguous()
+        g = graph if (graph is not None and not graph.pending) else None
+        if g is not None:
+            g.s.detach().copy_(s)
+            g.M.detach().copy_(M)
+            g.fwd.replay()
+            g.pending = True
+            s_l, M_l, Wm, shift = g.s, g.M, g.Wm, g.shift
+            Wm_c, shift_c = Wm.detach().float().clone(), shift.detach().float().contiguous()     # (Wm_c is saved for backward: its own copy)
+        else:
+            with torch.enable_grad():
+                s_l, M_l = s.requires_grad_(True), M.requires_grad_(True)
+                Wm, shift = algebra(s_l, M_l)
+            Wm_c, shift_c = Wm.detach().float().contiguous(), shift.detach().float().contiguous()
         y = _ga_call(x, Wm_c, shift=shift_c)
         ctx.save_for_backward(x, Wm_c)
         ctx.graph = (s_l, M_l, Wm, shift)
+        ctx.alg = g
         ctx.params = params
         return y
 
@@ -1302,21 +1360,45 @@ class _GroupWhiten(torch.autograd.Function):
         ctx.graph = None
         dy = _chk(dy, "dy")
         dshift, dWm = _gm_call(dy, x)
-        inputs = (s_l, M_l) + tuple(p for p in ctx.params if p.requires_grad)
-        grads = torch.autograd.grad((Wm, shift), inputs, (dWm.to(Wm.dtype), dshift.view_as(shift).to(shift.dtype)),
-                                    allow_unused=True)
+        g = ctx.alg
+        if g is not None:
+            g.dWm.copy_(dWm)
+            g.dshift.copy_(dshift.view_as(g.dshift))
+            g.bwd.replay()
+            g.pending = False
+            grads = tuple(t.detach().clone() if t is not None else None for t in g.grads)
+            inputs = g.inputs
+        else:
+            inputs = (s_l, M_l) + tuple(p for p in ctx.params if p.requires_grad)
+            grads = torch.autograd.grad((Wm, shift), inputs, (dWm.to(Wm.dtype), dshift.view_as(shift).to(shift.dtype)),
+                                        allow_unused=True)
         ds = grads[0] if grads[0] is not None else torch.zeros_like(s_l)
         dM = grads[1] if grads[1] is not None else torch.zeros_like(M_l)
         sym = (dM + dM.transpose(-1, -2)).float().contiguous()
         dx = _ga_call(dy, Wm_c.transpose(-1, -2).contiguous(), z=x, Vm=sym, shift=ds.float().contiguous())
         it = iter(grads[2:])
-        return (dx, None) + tuple(next(it) if p.requires_grad else None for p in ctx.params)
+        return (dx, None, None) + tuple(next(it) if p.requires_grad else None for p in ctx.params)
 
 
-def group_whiten(x, algebra, params):
+def group_whiten(x, algebra, params, graph=None):
     """y = apply(x, *algebra(sum_p x, sum_p x x^T per group)); `algebra(s [B,C], M [B,C/16,16,16]) -> (Wm [B,C/16,16,16],
-    shift [B,C])` is differentiable torch code over a few KB that may use the parameters `params`."""
-    return _GroupWhiten.apply(x, algebra, *params)
+    shift [B,C])` is differentiable torch code over a few KB that may use the parameters `params`.  `graph` = (owner module, hashable key of
+    everything the algebra bakes in besides `params` -- shape, mode --, the buffers it updates in place) lets the algebra run as two
+    captured hipGraphs (_AlgebraGraph); None: eager."""
+    g = None
+    if graph is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        owner, key, buffers = graph
+        cache = _ALG_GRAPHS.setdefault(owner, {})
+        key = key + tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in buffers)
+        g = cache.get(key)
+        if g is None:
+            # captured HERE, not inside the autograd Function (a capture begun inside Function.forward ends in a segmentation fault in
+            # hipStreamEndCapture on this stack), over well-conditioned stand-in inputs: zero sums, identity covariance
+            B, C, H, W = x.shape
+            s0 = torch.zeros(B, C, dtype=torch.float32, device=x.device)
+            M0 = (torch.eye(16, dtype=torch.float32, device=x.device) * float(H * W)).expand(B, C // 16, 16, 16).contiguous()
+            g = cache[key] = _AlgebraGraph(algebra, s0, M0, params, buffers)
+    return _GroupWhiten.apply(x, algebra, g, *params)
 
 
 # ------------------------------------------------------------------------------------------

@@ -143,6 +143,49 @@ def test_switch_whiten_group_kernels_match_generic_passes(sw_type, tie):
         assert relerr(a, b) < 5e-4
 
 
+@pytest.mark.parametrize("sw_type,tie", [(2, False), (5, True)])
+def test_switch_whiten_algebra_as_hipgraphs_is_bit_identical_to_the_eager_algebra(sw_type, tie, monkeypatch):
+    """ops._AlgebraGraph: the 16x16 algebra of a training SwitchWhiten2d replayed as two captured hipGraphs (forward, autograd.grad) --
+    the same kernels in the same order, so output, every gradient and the running statistics equal the eager path bit for bit over
+    three steps with changing input and parameters (the warm-up runs of the capture must not have touched the running statistics);
+    a second forward before the first backward falls back to the eager algebra and is still correct."""
+    from mrfp_amd.network.sync_switchwhiten import SwitchWhiten2d
+    res = []
+    for graph in ("1", "0"):
+        monkeypatch.setenv("MRFP_WHITEN_GRAPH", graph)
+        torch.manual_seed(5)
+        sw = SwitchWhiten2d(64, num_pergroup=16, sw_type=sw_type, T=5, tie_weight=tie).to(DEV).train()
+        with torch.no_grad():
+            sw.weight.uniform_(0.5, 1.5)
+            sw.bias.uniform_(-0.5, 0.5)
+            sw.sw_mean_weight.uniform_(-0.5, 0.5)
+        out = []
+        g = torch.Generator().manual_seed(9)
+        for step in range(3):
+            x = (torch.randn(4, 64, 12, 10, generator=g) * (1.0 + step) + 0.2).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            gy = torch.randn(4, 64, 12, 10, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+            for p in sw.parameters():
+                p.grad = None
+            y = sw(x)
+            y.backward(gy)
+            out += [y.detach().clone(), x.grad.clone(), sw.weight.grad.clone(), sw.bias.grad.clone(), sw.sw_mean_weight.grad.clone(),
+                    sw.running_mean.clone(), sw.running_cov.clone()]
+            with torch.no_grad():
+                for p in sw.parameters():
+                    p.sub_(0.05 * p.grad)
+        # two forwards of the layer before any backward (the second one must not disturb the first one's backward)
+        xa = torch.randn(4, 64, 12, 10, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        xb = torch.randn(4, 64, 12, 10, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ya, yb = sw(xa), sw(xb)
+        (ya.float().square().sum() + yb.float().sum()).backward()
+        out += [ya.detach().clone(), yb.detach().clone(), xa.grad.clone(), xb.grad.clone(), sw.running_cov.clone()]
+        res.append(out)
+        from mrfp_amd import ops
+        assert (len(ops._ALG_GRAPHS.get(sw, {})) == 1) == (graph == "1"), "one algebra graph per (layer, shape) when the switch is on, none when off"
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_group_isqrt_matches_newton_schulz_autograd():
     """mrfp_group_isqrt_{fwd,bwd} against the reference's Newton-Schulz loop differentiated by torch autograd."""
     from mrfp_amd import ops

@@ -1,32 +1,43 @@
-"""Which Python lines issue the device-to-device copies (`__amd_rocclr_copyBuffer`) of one train step?
-torch.profiler on the CPU side (aten::copy_ with stacks), ResNet-50 MRFP+ 4x256^2: gpurun -- python tools/find_copies.py"""
-import os, sys, contextlib, io, collections
+"""Which device-to-device copies (hipMemcpyAsync / __amd_rocclr_copyBuffer: Tensor.copy_, clone, contiguous, to) run inside a train step,
+and from where: torch.profiler with stacks, one step."""
+import collections
+import contextlib
+import io
+import os
+import sys
+
 import torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from mrfp_amd import synth, deepv3
-from mrfp_amd.config import cfg
-from mrfp_amd.harness import Trainer
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mrfp_amd import deepv3, synth  # noqa: E402
+from mrfp_amd.config import cfg  # noqa: E402
+from mrfp_amd.harness import Trainer  # noqa: E402
+
 cfg.MODEL.ACT_DTYPE = torch.bfloat16
 dev = torch.device("cuda", 0)
 with contextlib.redirect_stdout(io.StringIO()):
-    model = deepv3.MRFPPlus(19, trunk="resnet-50", criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
+    model = deepv3.MRFPPlus(19, trunk="resnet-101", criterion=torch.nn.CrossEntropyLoss(ignore_index=255))
 model.load_state_dict(synth.synth_state_dict(synth.spec_of(model.state_dict()), seed=0))
 model = model.to(dev).train()
 model.rng = deepv3.InjectedRandom((True, True, True), None, reinit=True)
-tr = Trainer(model)
-x, y = synth.synth_batch(4, 256, 256, seed=1)
+trainer = Trainer(model)
+x, y = synth.synth_batch(16, 768, 768, seed=1)
 x, y = x.to(dev), y.to(dev)
-for _ in range(3):
-    tr.step(x, y)
+for _ in range(2):
+    trainer.step(x, y)
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
-    tr.step(x, y)
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+    trainer.step(x, y)
     torch.cuda.synchronize()
-cnt = collections.Counter()
+names = collections.Counter()
+sites = collections.Counter()
 for e in prof.events():
-    if e.name.startswith("aten::") and e.name not in ("aten::empty", "aten::view", "aten::as_strided", "aten::empty_strided", "aten::reshape", "aten::slice", "aten::select", "aten::detach", "aten::alias", "aten::permute", "aten::empty_like", "aten::_unsafe_view", "aten::transpose", "aten::expand", "aten::unsqueeze", "aten::squeeze", "aten::t", "aten::narrow", "aten::contiguous", "aten::result_type", "aten::lift_fresh", "aten::resize_", "aten::set_", "aten::is_pinned", "aten::_has_compatible_shallow_copy_type", "aten::view_as", "aten::to", "aten::ones_like", "aten::zeros", "aten::zeros_like", "aten::clone", "aten::zero_", "aten::full_like", "aten::unflatten", "aten::flatten"):
-        st = [s for s in (e.stack or []) if "mrfp_amd" in s or "bench.py" in s]
-        cnt[(e.name, "", "")] += 1
-for (n, sh, s), c in cnt.most_common(40):
-    print("%4d %-14s %-60s %s" % (c, n, sh, s))
+    if e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::fill_", "aten::zero_", "aten::add_", "aten::mul", "aten::add", "aten::mul_"):
+        st = [s for s in (e.stack or []) if "/mrfp_amd/" in s or "bench.py" in s]
+        sites[(e.key, str(e.input_shapes)[:60], st[0][-90:] if st else "?")] += 1
+    names[e.key] += 1
+for (k, sh, s), c in sorted(sites.items(), key=lambda kv: -kv[1])[:50]:
+    print("x%-4d %-16s %-62s %s" % (c, k, sh, s))
+print({k: v for k, v in names.items() if "Memcpy" in k or "copy" in k.lower()})

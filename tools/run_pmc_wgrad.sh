@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/run_pmc_wgrad.sh'   -> gpurun_out/pmcw_*.txt   (each counter group in its own rocprofv3 pass)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for idx in 0 2 6; do
+for idx in ${WG_IDX:-0 2 6}; do
   O=$R/gpurun_out/pmcw_$idx; rm -rf $O; mkdir -p $O
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/a -o p -- python3 $R/tools/wgrad_micro.py 3 $idx grouped > $O/a.log 2>&1 || exit 1
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT --output-format csv -d $O/b -o p -- python3 $R/tools/wgrad_micro.py 3 $idx grouped > $O/b.log 2>&1 || exit 1
@@ -20,7 +20,7 @@ for grp in "abcfw":
         per = defaultdict(lambda: defaultdict(float))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "wgrad" not in k: continue
+            if "wgrad" not in k and "wg3" not in k: continue
             per[(k.split("(")[0][-70:], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
         for (k, _), cs in per.items():
             for c, v in cs.items(): acc[k][c].append(v)

@@ -17,7 +17,8 @@ SHAPES = [(16, 48, 48, 256, 1024, 1, 1, 0, 1, 23), (16, 48, 48, 1024, 256, 1, 1,
           (16, 48, 48, 512, 512, 3, 1, 2, 2, 3), (16, 48, 48, 512, 2048, 1, 1, 0, 1, 3), (16, 48, 48, 2048, 512, 1, 1, 0, 1, 2),
           (16, 192, 192, 256, 256, 3, 1, 1, 1, 1), (16, 192, 192, 320, 256, 3, 1, 1, 1, 1), (16, 48, 48, 2048, 256, 3, 1, 12, 12, 1),
           (16, 48, 48, 1024, 2048, 1, 1, 0, 1, 1), (16, 96, 96, 128, 512, 1, 1, 0, 1, 4), (16, 96, 96, 512, 128, 1, 1, 0, 1, 3),
-          (16, 192, 192, 64, 256, 1, 1, 0, 1, 3), (16, 96, 96, 512, 256, 1, 1, 0, 1, 1), (16, 48, 48, 1280, 256, 1, 1, 0, 1, 1)]
+          (16, 192, 192, 64, 256, 1, 1, 0, 1, 3), (16, 96, 96, 512, 256, 1, 1, 0, 1, 1), (16, 48, 48, 1280, 256, 1, 1, 0, 1, 1),
+          (16, 384, 384, 64, 64, 3, 1, 1, 1, 1), (16, 384, 384, 64, 128, 3, 1, 1, 1, 1), (16, 192, 192, 64, 64, 3, 1, 1, 1, 3), (16, 96, 96, 128, 128, 3, 1, 1, 1, 3)]
 L = _lib.lib()
 if len(sys.argv) > 2:
     SHAPES = [SHAPES[int(sys.argv[2])]]
