@@ -380,7 +380,8 @@ def test_accumulator_stationary_3x3_wgrad_in_subprocess():
         "import test_conv_gpu as t\n"
         "for (B,C,H,W,N,dil,n,Ct,dt) in [(2,64,16,64,64,1,1,64,'b'),(1,64,24,128,128,1,1,64,'b'),(2,128,12,96,128,1,3,128,'b'),(2,64,8,48,64,1,1,64,'b'),"
         "(2,128,16,48,256,2,2,128,'b'),(2,64,20,64,128,2,1,64,'h'),(2,320,12,64,256,1,1,304,'b'),(3,64,40,192,64,1,1,64,'b'),(5,128,40,64,128,1,7,128,'b'),"
-        "(4,256,48,48,256,1,22,256,'b'),(2,128,24,96,64,2,2,128,'h')]:\n"
+        "(4,256,48,48,256,1,22,256,'b'),(2,128,24,96,64,2,2,128,'h'),(1,64,4,144,64,1,1,64,'b'),(2,64,8,144,128,2,1,64,'b'),(1,128,2,64,64,1,32,128,'b'),"
+        "(4,128,48,192,128,1,5,128,'b'),(16,64,96,192,64,1,3,64,'b')]:\n"
         "    g = torch.Generator(device='cuda:0').manual_seed(3)\n"
         "    dtype = torch.bfloat16 if dt == 'b' else torch.float16\n"
         "    xs, dys = [], []\n"
