@@ -313,6 +313,13 @@ bool wg3_applicable(int dtype_size, int64_t B, int64_t H, int64_t W, int64_t C, 
 int wg3_run(const void* const* xs, const void* const* dys, int64_t count, float* slab, bool is_f16, int64_t B, int64_t H, int64_t W, int64_t C,
             int64_t N, int64_t ldn, int64_t dil, unsigned xbytes, unsigned dybytes, int* splits, hipStream_t st);
 
+// accumulator-stationary weight gradient of the pointwise layers with C % 256 == N % 256 == 0 (conv_wg1.hip)
+int64_t wg1_splits_bound(int64_t N, int64_t Q, int64_t count);
+bool wg1_applicable(int dtype_size, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho,
+                    int64_t Wo, int64_t stride, int64_t pad_h, int64_t pad_w, int64_t count);
+int wg1_run(const void* const* xs, const void* const* dys, int64_t count, float* slab, bool is_f16, int64_t M, int64_t C, int64_t N, int64_t ldn,
+            unsigned xbytes, unsigned dybytes, int* splits, hipStream_t st);
+
 bool c64_applicable(const ConvP& p, int esz);
 int64_t c64_stats_blocks(const ConvP& p);             // statistics rows such a launch writes: [image][sub-strip][slot]
 int64_t c64_stats_block_rows(const ConvP& p);         // NEGATIVE: -(rows per image) -- the rows are per image, not per fixed row count

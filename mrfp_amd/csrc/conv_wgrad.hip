@@ -555,6 +555,8 @@ int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q) {
     if (s64p > s64) s64 = s64p;
     const int64_t s3 = mrfp::wg3_splits_bound(N, Q, 1);       // the accumulator-stationary 3x3 kernel (conv_wg3.hip), if Q could be 9 * C
     if (s3 > s64) s64 = (int)s3;
+    const int64_t s1 = mrfp::wg1_splits_bound(N, Q, 1);       // ... and the pointwise one (conv_wg1.hip)
+    if (s1 > s64) s64 = (int)s1;
     return (int64_t)(s32 > s64 ? s32 : s64) * N * Q * 4;
 }
 
@@ -614,6 +616,8 @@ static int wgrad_run(const void* const* xs, const void* const* dys, float* const
         int rc;
         if (bc == B && !dbg_drop && wg3_applicable(esz, B, H, W, C, N, ldn, R, S, Ho, Wo, stride, pad_h, pad_w, dil, count))
             rc = wg3_run(xs, dys, count, (float*)ws, dtype == MRFP_F16, B, H, W, C, N, ldn, dil, p.xbytes, p.dybytes, &splits, st);
+        else if (bc == B && !dbg_drop && wg1_applicable(esz, B, H, W, C, N, ldn, R, S, Ho, Wo, stride, pad_h, pad_w, count))
+            rc = wg1_run(xs, dys, count, (float*)ws, dtype == MRFP_F16, B * H * W, C, N, ldn, p.xbytes, p.dybytes, &splits, st);
         else if (dtype == MRFP_F32) rc = wm == 1 ? launch_wgrad<float, 1, 4>(p, splits, st, &grp) : launch_wgrad<float, 2, 2>(p, splits, st, &grp);
         else if (dtype == MRFP_F16) rc = wm == 1 ? launch_wgrad<f16, 1, 4>(p, splits, st, &grp) : launch_wgrad<f16, 2, 2>(p, splits, st, &grp, tmb);
         else rc = wm == 1 ? launch_wgrad<bf16, 1, 4>(p, splits, st, &grp) : launch_wgrad<bf16, 2, 2>(p, splits, st, &grp, tmb);
@@ -644,6 +648,8 @@ int64_t mrfp_conv_wgrad_grouped_ws_bytes(int64_t M, int64_t N, int64_t Q, int64_
     if (s64p > s64) s64 = s64p;
     const int64_t s3 = mrfp::wg3_splits_bound(N, Q, count);
     if (s3 > s64) s64 = (int)s3;
+    const int64_t s1 = mrfp::wg1_splits_bound(N, Q, count);
+    if (s1 > s64) s64 = (int)s1;
     return (int64_t)(s32 > s64 ? s32 : s64) * count * N * Q * 4;
 }
 

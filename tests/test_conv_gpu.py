@@ -404,6 +404,40 @@ def test_accumulator_stationary_3x3_wgrad_in_subprocess():
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_accumulator_stationary_pointwise_wgrad_in_subprocess():
+    """conv_wg1_kernel (csrc/conv_wg1.hip): the weight gradient of the pointwise layers with C % 256 == N % 256 == 0 with dW[256 n][256 c] held in
+    the accumulators of a 512-thread workgroup and the pixels streamed through a ring of four stages, forced wherever it is legal
+    (MRFP_WGRAD1=2; read once per process): one and several channel blocks on either side, single and grouped launches, main chunks only and
+    main + remainder workgroups, rings shorter than their depth (1 and 2 units), bf16 and f16 -- against torch's convolution gradient of the
+    same rounded operands, bit-identical between two launches."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import test_conv_gpu as t\n"
+        "for (B,C,H,W,N,n,dt) in [(2,256,8,16,256,1,'b'),(1,512,16,16,256,3,'b'),(2,256,12,16,1024,5,'b'),(4,1024,48,48,256,22,'b'),(2,256,10,16,256,1,'h'),"
+        "(1,2048,8,8,512,2,'b'),(1,256,4,8,256,1,'b'),(4,256,48,48,1024,23,'b'),(2,512,24,24,2048,3,'h')]:\n"
+        "    g = torch.Generator(device='cuda:0').manual_seed(3)\n"
+        "    dtype = torch.bfloat16 if dt == 'b' else torch.float16\n"
+        "    xs = [torch.randn(B,H,W,C,device='cuda:0',generator=g).to(dtype).permute(0,3,1,2) for _ in range(n)]\n"
+        "    dys = [(torch.randn(B,H,W,N,device='cuda:0',generator=g) * (0.25 if dt == 'h' else 1.0)).to(dtype).permute(0,3,1,2) for _ in range(n)]\n"
+        "    a = t._wgrad_grouped(xs,dys,N,C,1,1,0,1) if n > 1 else [t._wgrad_single(xs[0],dys[0],N,C,1,1,0,1)]\n"
+        "    b = t._wgrad_grouped(xs,dys,N,C,1,1,0,1) if n > 1 else [t._wgrad_single(xs[0],dys[0],N,C,1,1,0,1)]\n"
+        "    for i in range(n):\n"
+        "        assert torch.equal(a[i], b[i]) and torch.isfinite(a[i]).all(), (C, N, H, W, i)\n"
+        "        if i in (0, n - 1):\n"
+        "            ref = torch.nn.grad.conv2d_weight(xs[i].float().cpu(), (N,C,1,1), dys[i].float().cpu(), 1, 0, 1)\n"
+        "            assert t.relerr(a[i], ref) < 1e-4, (C, N, H, W, i, t.relerr(a[i], ref))\n"
+        "print('ok')\n") % os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"MRFP_WGRAD1": "2"}, {"MRFP_WGRAD1": "0"}):
+        env = dict(os.environ, PYTHONPATH=root, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_wgrad_256x128_tile_in_subprocess():
     """conv_wgrad_kernel<..., TMB = 4>: the 256 x 128 weight-gradient tile (16-bit LDS-DMA kernels, N % 256 == 0) forced wherever
     it is legal (MRFP_WGRAD_BIG=2; the switch is read once per process) -- single and grouped launches, dense (pointwise) and
