@@ -68,6 +68,35 @@ def test_fourier_and_whitening_host_queries(cdll):
     assert cdll.mrfp_group_isqrt_fwd(None, None, 1, 5, None) != 0 and b"group_isqrt" in cdll.mrfp_last_error()
 
 
+def test_wgrad_workspace_covers_the_accumulator_stationary_kernels(cdll):
+    """mrfp_conv_wgrad_ws_bytes / _grouped_ws_bytes know (M, N, Q, count) only: the workspace must hold the slab slots of whichever kernel the launch
+    picks -- conv_wgrad_kernel's K' splits, or, for the accumulator-stationary kernels (csrc/conv_wg3.hip: 64 x 9 x 64 classes over 512 workgroups;
+    csrc/conv_wg1.hip: 256 x 256 classes over 256), `main chunks per class` + 2 remainder slots per problem."""
+    one, grp = cdll.mrfp_conv_wgrad_ws_bytes, cdll.mrfp_conv_wgrad_grouped_ws_bytes
+    for f in (one, grp):
+        f.restype = ctypes.c_int64
+    one.argtypes = [ctypes.c_int64] * 3
+    grp.argtypes = [ctypes.c_int64] * 4
+
+    def slots3(N, Q, count):
+        ncls = (N // 64) * (Q // 576)
+        a = (512 // count) // ncls
+        return a + 2 if a >= 1 else 0
+
+    def slots1(N, Q, count):
+        ncls = (N // 256) * (Q // 256)
+        a = (256 // count) // ncls
+        return a + 2 if a >= 1 else 0
+    for M, N, Q, count in [(16 * 384 * 384, 64, 576, 1), (16 * 384 * 384, 128, 576, 1), (16 * 192 * 192, 256, 2304, 1), (16 * 192 * 192, 256, 2880, 1),
+                           (36864, 256, 2304, 22), (36864, 512, 4608, 3), (16 * 192 * 192, 64, 576, 3), (16 * 96 * 96, 128, 1152, 3)]:
+        got = int(grp(M, N, Q, count)) if count > 1 else int(one(M, N, Q))
+        assert got % (N * Q * 4) == 0 and got >= slots3(N, Q, count) * count * N * Q * 4, (M, N, Q, count, got)
+    for M, N, Q, count in [(36864, 1024, 256, 23), (36864, 256, 1024, 22), (36864, 2048, 512, 3), (36864, 512, 2048, 2), (36864, 2048, 1024, 1)]:
+        got = int(grp(M, N, Q, count)) if count > 1 else int(one(M, N, Q))
+        assert got % (N * Q * 4) == 0 and got >= slots1(N, Q, count) * count * N * Q * 4, (M, N, Q, count, got)
+    assert int(one(36864, 19, 256)) > 0 and int(grp(36864, 19, 256, 32)) > 0         # shapes neither kernel takes still get their splits
+
+
 def test_nearest_tables_match_aten():
     """The host-side index tables the kernels consume == F.interpolate(mode='nearest')."""
     import numpy as np
