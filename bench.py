@@ -494,7 +494,7 @@ def step_roofline(model, trainer, x, y, args):
             json.dump([{"name": c["name"], "args": c["args"], "group": c["group"], "ms": c["ms"], "gflop": c["flop"] / 1e9, "mbytes": c["bytes"] / 1e6,
                         "tflops": c["flop"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0} for c in convs], f)
     ach = tot_f / (tot_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_c64_kernel+conv1x1_bstat_kernel+conv1x1_longk*_kernel+conv_wgrad_kernel+conv_wg3_kernel (all %d conv launches of one step, %d weight-gradient problems in them)"
+    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_c64_kernel+conv1x1_bstat_kernel+conv1x1_longk*_kernel+conv_wgrad_kernel+conv_wg3_kernel+conv_wg1_kernel (all %d conv launches of one step, %d weight-gradient problems in them)"
             % (len(convs), sum(c["group"] for c in convs if c["name"] == "mrfp_conv_wgrad")),
             "achieved": round(ach, 2), "peak": peak_f, "unit": "TFLOP/s", "frac": round(ach / peak_f, 4),
             "traffic": None, "conv_ms_per_step": round(tot_ms, 3), "conv_tflop_per_step": round(tot_f / 1e12, 3)}
