@@ -98,7 +98,14 @@ __device__ __forceinline__ void ac_range(int in, int out, int src, int& lo, int&
 // KW = compile-time bound on the number of destination columns that can touch one source column (0: unbounded,
 // plain nested loops).  With a bound the column weights are computed once per source pixel and the KW loads of a
 // destination row are issued together; the accumulation order (rows outer, columns inner) is the same in both forms.
-template <typename T, int VEC, int KW>
+// KN (round 5; 0: off) = a tighter compile-time bound on the destination columns that carry a NON-ZERO weight for one source column: the open
+// interval ((iw-1)/sw, (iw+1)/sw) holds at most kw - 2 of the kw candidates ac_range() brackets it with -- 5 of 8 slots at a 2x upsample, 9 of 12
+// at 4x -- and they are consecutive, starting at candidate 0 or 1.  The kernel is bound by its instruction stream (a slot costs a 16-byte load,
+// VEC conversions and 2 VEC arithmetic instructions whether its weight is zero or not: ~1 000 vector instructions per 16 output bytes at 2x), so
+// only the window is evaluated, its last slot under a branch that is rarely taken (a fifth non-zero column occurs for ~0.5 % of the source
+// columns at 2.0026x).  The same non-zero products in the same order: bit-identical output.  A float position that rounds onto the interval's
+// boundary can put a ~1 ulp weight outside the window: the candidates behind it are checked, and a wave that sees one takes the full loop.
+template <typename T, int VEC, int KW, int KN = 0>
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
                                                                 int Hi, int Wi, int Ho, int Wo, int C, int ldi, int ly, int ldd) {
     const int b = blockIdx.x / ly, j = blockIdx.x % ly;
@@ -117,7 +124,44 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const T* __restr
                 float acc[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-                if (KW > 0) {
+                bool windowed = false;
+                if constexpr (KW > 0 && KN > 0) {
+                    const int kf = ac_weight(sw, ow0, Wi, iw) != 0.f ? 0 : 1;       // first candidate with a weight
+                    float wn[KN > 0 ? KN : 1];
+#pragma unroll
+                    for (int k = 0; k < KN; ++k) wn[k] = (ow0 + kf + k <= ow1) ? ac_weight(sw, ow0 + kf + k, Wi, iw) : 0.f;
+                    bool more = false;                                              // a weight behind the window (boundary rounding)?
+#pragma unroll
+                    for (int k = KN; k < KW; ++k) more = more || (ow0 + kf + k <= ow1 && ac_weight(sw, ow0 + kf + k, Wi, iw) != 0.f);
+                    if (__builtin_amdgcn_ballot_w64(more) == 0) {
+                        windowed = true;
+                        for (int oh = oh0; oh <= oh1; ++oh) {
+                            const float wh = ac_weight(sh, oh, Hi, ih);
+                            if (wh == 0.f) continue;
+                            const T* dl = dy + ((size_t)b * Ho + oh) * Wo * ldd + (size_t)cv * VEC;
+                            VecT<T, VEC> r[KN > 0 ? KN : 1];
+#pragma unroll
+                            for (int k = 0; k < KN; ++k) r[k] = load_raw<T, VEC>(dl + (size_t)min(ow0 + kf + k, ow1) * ldd);
+#pragma unroll
+                            for (int k = 0; k < KN - 1; ++k) {
+                                const float w = wh * wn[k];
+                                float dv[VEC];
+                                cvt_f<T, VEC>(r[k], dv);
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) acc[i] += (wn[k] != 0.f) ? w * dv[i] : 0.f;
+                            }
+                            if (wn[KN - 1] != 0.f) {
+                                const float w = wh * wn[KN - 1];
+                                float dv[VEC];
+                                cvt_f<T, VEC>(r[KN - 1], dv);
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) acc[i] += w * dv[i];
+                            }
+                        }
+                    }
+                }
+                if (windowed) {
+                } else if (KW > 0) {
                     float ww[KW > 0 ? KW : 1];
 #pragma unroll
                     for (int k = 0; k < KW; ++k) ww[k] = (ow0 + k <= ow1) ? ac_weight(sw, ow0 + k, Wi, iw) : 0.f;
@@ -451,12 +495,16 @@ static int do_bilinear_bwd(const void* dy, void* dx, int64_t B, int64_t Hi, int6
     const dim3 grid((unsigned)(B * ly));
     const int full = FullVec<T>::value;
     const bool vec = ok && pick_vec<T>(C) > 1;
-#define MRFP_BWD_LAUNCH(VECV, KWV)                                                                                     \
-    hipLaunchKernelGGL((bilinear_bwd_kernel<T, VECV, KWV>), grid, dim3(kThreads), 0, st, (const T*)dy, (T*)dx, (int)B, \
+#define MRFP_BWD_LAUNCH(VECV, KWV, ...)                                                                                     \
+    hipLaunchKernelGGL((bilinear_bwd_kernel<T, VECV, KWV, ##__VA_ARGS__>), grid, dim3(kThreads), 0, st, (const T*)dy, (T*)dx, (int)B, \
                        (int)Hi, (int)Wi, (int)Ho, (int)Wo, (int)C, (int)ldi, ly, (int)ldd)
+    static int win = -1;          // MRFP_BILINEAR_WINDOW=0: every candidate column evaluated (A/B runs, the bit-identity test)
+    if (win < 0) { const char* e = getenv("MRFP_BILINEAR_WINDOW"); win = e ? atoi(e) : 1; }
     if (vec) {
         if (kw <= 4) MRFP_BWD_LAUNCH(full, 4);
+        else if (kw == 7 && win) MRFP_BWD_LAUNCH(full, 8, 5);          // 2x (the loss head, the class-score upsample): 5 of 8 slots
         else if (kw <= 8) MRFP_BWD_LAUNCH(full, 8);
+        else if (kw == 11 && win) MRFP_BWD_LAUNCH(full, 12, 9);        // 4x (the decoder): 9 of 12
         else if (kw <= 12) MRFP_BWD_LAUNCH(full, 12);
         else MRFP_BWD_LAUNCH(full, 0);
     } else {

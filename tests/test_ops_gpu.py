@@ -226,6 +226,43 @@ def test_bilinear(dtype, case):
         assert relerr(ad.grad, ac.grad) < t
 
 
+def test_bilinear_backward_over_the_window_of_nonzero_columns_equals_the_full_loop(tmp_path):
+    """bilinear_bwd_kernel<T, VEC, KW, KN> (csrc/resize_pool.hip, round 5): at a 2x / 4x upsample only the 5 of 8 / 9 of 12 candidate destination
+    columns that can carry a weight are evaluated.  Against the full loop (MRFP_BILINEAR_WINDOW=0, child process: the switch is read once): the same
+    non-zero products in the same order -- bit-identical -- and against the CPU restatement."""
+    import os
+    import subprocess
+    import sys
+    o = ops()
+    cases = [((1, 32, 48, 48), (96, 96)), ((1, 64, 12, 12), (48, 48)), ((2, 24, 96, 96), (192, 192)), ((1, 256, 12, 12), (24, 24)), ((1, 8, 31, 57), (61, 113))]
+    code = ("import sys, torch\nsys.path.insert(0, %r)\nfrom mrfp_amd import ops\nout = []\n"
+            "for (shape, size) in %r:\n"
+            "    for dtype in (torch.bfloat16, torch.float32):\n"
+            "        g = torch.Generator().manual_seed(7)\n"
+            "        x = torch.randn(*shape, generator=g).to('cuda:0', dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)\n"
+            "        gy = torch.randn(shape[0], shape[1], *size, generator=g).to('cuda:0', dtype).contiguous(memory_format=torch.channels_last)\n"
+            "        ops.upsample_bilinear(x, size).backward(gy)\n"
+            "        out.append(x.grad.cpu())\n"
+            "torch.save(out, sys.argv[1])\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases)
+    files = []
+    for tag, env in (("window", {}), ("full", {"MRFP_BILINEAR_WINDOW": "0"})):
+        f = str(tmp_path / (tag + ".pt"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        files.append(torch.load(f))
+    for a, b in zip(*files):
+        assert torch.equal(a, b)
+    i = 0
+    for shape, size in cases:
+        for dtype in (torch.bfloat16, torch.float32):
+            g = torch.Generator().manual_seed(7)
+            x = torch.randn(*shape, generator=g).to(dtype).float().requires_grad_(True)
+            gy = torch.randn(shape[0], shape[1], *size, generator=g).to(dtype).float()
+            orc.upsample_bilinear_ac(x, size).backward(gy)
+            assert relerr(files[0][i], x.grad) < 4 * tol(dtype)
+            i += 1
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (2, 64, 17, 13), (1, 8, 1, 1), (2, 128, 2, 5)])
 def test_maxpool(dtype, shape):
