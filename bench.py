@@ -542,6 +542,10 @@ def step_roofline(model, trainer, x, y, args):
                          "achieved_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["bytes"] > 0 else None,
                          "bound": "hbm" if v["bytes"] > 0 else "launch"}
                      for k, v in sorted(other.items(), key=lambda kv: -kv[1]["ms"])}
+    # the re-pack launch follows the optimizer step, which waits for the weight-gradient stream: its INTERVAL on the main stream is mostly
+    # that wait (the kernel itself: ~0.13 ms, profiles/r05_bench_kernel_stats.md) -- say so next to the number
+    if "mrfp_pack_weights_batched" in roof["other"]:
+        roof["other"]["mrfp_pack_weights_batched"]["note"] = "interval on the main stream: includes waiting for the weight-gradient stream behind the SGD step; kernel time ~0.13 ms"
     return roof
 
 
