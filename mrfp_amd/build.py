@@ -88,7 +88,7 @@ def build_variant(name: str, units, flags) -> str:
 
 
 # conservative-wait build: every counted `s_waitcnt vmcnt(N)` of the asynchronous LDS-DMA rings is vmcnt(0) (conv_common.hpp)
-VM0_UNITS = ("conv_pw", "conv_pwk", "conv_c64", "conv_wgrad")
+VM0_UNITS = ("conv_pw", "conv_pwk", "conv_c64", "conv_wgrad", "conv_wg1")
 
 
 def build_vm0() -> str:
