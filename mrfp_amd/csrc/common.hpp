@@ -117,6 +117,8 @@ struct RowGeom {
 };
 
 constexpr int kThreads = 256;
+constexpr int kCUs = 256;        // compute units of one MI355X (MI355X_MICROARCH.md, chip-level parameters): what "one round of resident
+                                 // workgroups" means to the persistent kernels (conv_common.hpp: kGrid1PerCU / kGrid2PerCU; whiten.hip)
 
 struct Lanes {
     int lpr;         // channel vectors per row = C / VEC

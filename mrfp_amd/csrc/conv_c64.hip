@@ -304,7 +304,7 @@ bool c64_applicable(const ConvP& p, int esz) {
         // one workgroup per CU that first loads 288 registers of weights per wave: it pays from ~32 output row strips per workgroup on
         // (measured in the step: 128 -> 64 @256^2 188 -> 133 us, @192^2 105 -> 130 us; 128 -> 128 @96^2 52 -> 64 us).  MRFP_CONV_C128=2: always (tests)
         const int SW = p.N == 64 ? 128 : 64;
-        if (c128 < 2 && (int64_t)p.B * ((p.W + SW - 1) / SW) * p.H < 32 * 256) return false;
+        if (c128 < 2 && (int64_t)p.B * ((p.W + SW - 1) / SW) * p.H < 32 * kGrid1PerCU) return false;
     } else return false;
     if (p.addend_mask || (p.colstats && p.addend)) return false;
     if ((int64_t)p.M * p.ldy * esz >= (int64_t)kOOB || p.H < 2 * p.dil) return false;
@@ -313,7 +313,7 @@ bool c64_applicable(const ConvP& p, int esz) {
 static int c64_grid(const ConvP& p) {
     const int SW = p.N == 64 ? 128 : 64;
     const int64_t units = (int64_t)p.B * ((p.W + SW - 1) / SW) * p.H;
-    const int64_t cap = p.C == 64 ? 512 : 256;     // two workgroups per CU (64 channels) / one (128: 512 registers per wave)
+    const int64_t cap = p.C == 64 ? kGrid2PerCU : kGrid1PerCU;     // two workgroups per CU (64 channels) / one (128: 512 registers per wave)
     return (int)(units < cap ? units : cap);       // every workgroup owns at least one row strip
 }
 // statistics row slots per image and pixel sub-strip: an upper bound of the workgroups whose span touches one image
@@ -358,6 +358,11 @@ static int c64_run_t(const ConvP& p, hipStream_t st) {
     q.spi = c64_spi(p);
     q.xbytes = p.xbytes; q.wbytes = p.wbytes; q.ybytes = (unsigned)((int64_t)p.M * p.ldy * 2);
     const int grid = c64_grid(p);
+    // the statistics rows the caller sized through c64_stats_blocks() hold spi slots per image and sub-strip: the longest run of
+    // workgroups whose spans touch one image must fit (spans are units / grid or one more long)
+    const int64_t upi = (int64_t)q.strips * p.H, lmin = q.units / grid;
+    MRFP_CHECK(grid >= 1 && lmin >= 1 && upi / lmin + 2 <= q.spi && (int64_t)p.B * (p.N == 64 ? 2 : 1) * q.spi == c64_stats_blocks(p),
+               "conv_c64: grid %d / %d statistics slots per image do not match the workspace rule", grid, q.spi);
     if (p.C == 64) return p.N == 64 ? c64_pick<T, 1, 2>(p, q, grid, st) : c64_pick<T, 1, 4>(p, q, grid, st);
     return p.N == 64 ? c64_pick<T, 2, 2>(p, q, grid, st) : c64_pick<T, 2, 4>(p, q, grid, st);
 }

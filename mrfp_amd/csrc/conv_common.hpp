@@ -22,6 +22,14 @@
 
 namespace mrfp {
 
+// Launch geometry of the PERSISTENT kernels (conv_c64.hip, conv_wg3.hip, conv_wg1.hip): their grids are "one round" of resident
+// workgroups, and the statistics / slab buffers their callers allocate (c64_spi, wg3_splits_bound, wg1_splits_bound,
+// mrfp_conv_wgrad*_ws_bytes) are sized FROM these grids -- every such rule derives from the two constants below, and each *_run checks
+// its chosen split / span count against the bound function before it launches (an error, never a write past a buffer sized elsewhere).
+//   (kCUs: common.hpp)
+constexpr int kGrid1PerCU = kCUs;               // one resident workgroup per CU (512-register waves: conv_c64 at 128 channels, conv_wg1)
+constexpr int kGrid2PerCU = 2 * kCUs;           // two per CU (conv_c64 at 64 channels, conv_wg3)
+
 constexpr int kStampSlots = 4096;
 #if MRFP_CLOCK_STAMP
 struct ClockStamp {

@@ -190,7 +190,7 @@ static bool wg1_plan(int64_t M, int64_t C, int64_t N, int64_t count, Wg1Plan& pl
     const int64_t U = M / 32;
     if (U >= (1LL << 30)) return false;
     pl.U = (int)U;
-    pl.Wp = (int)(256 / count);                  // one 512-thread workgroup per CU, one round
+    pl.Wp = (int)(kGrid1PerCU / count);          // one 512-thread workgroup per CU, one round
     if ((int64_t)pl.ncls * U < pl.Wp) pl.Wp = (int)((int64_t)pl.ncls * U);
     pl.a = pl.Wp / pl.ncls;
     if (pl.a < 1) return false;
@@ -205,7 +205,7 @@ static bool wg1_plan(int64_t M, int64_t C, int64_t N, int64_t count, Wg1Plan& pl
 int64_t wg1_splits_bound(int64_t N, int64_t Q, int64_t count) {
     if (wg1_mode() == 0 || Q % 256 || N % 256 || count < 1) return 0;
     const int64_t ncls = (N / 256) * (Q / 256);
-    const int64_t a = (256 / count) / ncls;
+    const int64_t a = (kGrid1PerCU / count) / ncls;
     return a < 1 ? 0 : a + 2;
 }
 bool wg1_applicable(int dtype_size, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho,
@@ -236,6 +236,10 @@ int wg1_run(const void* const* xs, const void* const* dys, int64_t count, float*
             unsigned xbytes, unsigned dybytes, int* splits, hipStream_t st) {
     Wg1Plan pl;
     if (!wg1_plan(M, C, N, count, pl)) return -1;
+    // the slab the caller sized through wg1_splits_bound() holds that many slots per problem
+    MRFP_CHECK(pl.splits <= wg1_splits_bound(N, C, count) && (int64_t)count * pl.Wp <= kGrid1PerCU,
+               "conv_wg1: %d slab slots per problem / %lld workgroups exceed the workspace rule (%lld)", pl.splits,
+               (long long)(count * pl.Wp), (long long)wg1_splits_bound(N, C, count));
     Wg1P q;
     q.slab = slab;
     q.C = (int)C; q.N = (int)N; q.ldn = (int)ldn;

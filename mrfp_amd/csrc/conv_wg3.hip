@@ -277,7 +277,7 @@ static bool wg3_plan(int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int6
     const int64_t U = B * pl.strips * dil * pl.ups;
     if (U >= (1LL << 30)) return false;
     pl.U = (int)U;
-    pl.Wp = (int)(512 / count);                  // two workgroups per CU, one round
+    pl.Wp = (int)(kGrid2PerCU / count);          // two workgroups per CU, one round
     if ((int64_t)pl.ncls * U < pl.Wp) pl.Wp = (int)((int64_t)pl.ncls * U);
     pl.a = pl.Wp / pl.ncls;
     if (pl.a < 1) return false;                  // fewer workgroups than classes: no side-by-side walk
@@ -293,7 +293,7 @@ static bool wg3_plan(int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int6
 int64_t wg3_splits_bound(int64_t N, int64_t Q, int64_t count) {
     if (wg3_mode() == 0 || Q % (9 * 64) || N % 64 || count < 1) return 0;
     const int64_t ncls = (N / 64) * (Q / (9 * 64));
-    const int64_t a = (512 / count) / ncls;
+    const int64_t a = (kGrid2PerCU / count) / ncls;
     return a < 1 ? 0 : a + 2;
 }
 bool wg3_applicable(int dtype_size, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int64_t ldn, int64_t R, int64_t S, int64_t Ho,
@@ -333,6 +333,10 @@ int wg3_run(const void* const* xs, const void* const* dys, int64_t count, float*
             int64_t N, int64_t ldn, int64_t dil, unsigned xbytes, unsigned dybytes, int* splits, hipStream_t st) {
     Wg3Plan pl;
     if (!wg3_plan(B, H, W, C, N, dil, count, pl) || count > kWg3MaxGroup) return -1;
+    // the slab the caller sized through wg3_splits_bound() holds that many slots per problem
+    MRFP_CHECK(pl.splits <= wg3_splits_bound(N, 9 * C, count) && (int64_t)count * pl.Wp <= kGrid2PerCU,
+               "conv_wg3: %d slab slots per problem / %lld workgroups exceed the workspace rule (%lld)", pl.splits,
+               (long long)(count * pl.Wp), (long long)wg3_splits_bound(N, 9 * C, count));
     Wg3P q;
     q.slab = slab;
     q.B = (int)B; q.H = (int)H; q.W = (int)W; q.C = (int)C; q.N = (int)N; q.ldn = (int)ldn; q.d = (int)dil;

@@ -419,7 +419,7 @@ static int run_moments(const void* a, const void* b, float* M, float* sum_a, flo
             // short ones: pixel chunks of whole 32-pixel tiles, never more chunks than the workspace was sized for (g.nch).  Swept at
             // 16 x 256 x 192^2 (profiles/r05_whitening.md): 256 / 384 / 512 / 640 / 768 / 1024 / 2048 workgroups -> (x,x) 3.9 / 4.7 / 5.1 / 4.7 / 4.5 / 4.2 / 3.2 TB/s
             static int wgs = -1;
-            if (wgs < 0) { const char* e = getenv("MRFP_WHITEN_WGS"); wgs = e ? atoi(e) : 512; if (wgs < 64) wgs = 512; }
+            if (wgs < 0) { const char* e = getenv("MRFP_WHITEN_WGS"); wgs = e ? atoi(e) : 2 * kCUs; if (wgs < 64) wgs = 2 * kCUs; }
             const int slabs = (int)((C + kMmSlab - 1) / kMmSlab);
             int64_t want = (a == b ? wgs : wgs * 3 / 4) / (B * slabs);      // (a != b: two register sets of two operands, 3 per CU)
             if (want < 1) want = 1;

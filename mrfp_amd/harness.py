@@ -335,9 +335,11 @@ class Trainer:
             return self._graph_step(img, label)
         loss = self._fwd_bwd(img, label)
         gscale = self.sync.finish()
-        from . import conv
+        from . import conv, ops
         conv.join_wgrad_stream()                       # weight gradients are computed on a second stream
         self.opt.step(gscale / self.loss_scale)
+        if ops._SYNC_BN_FLAG:                          # cfg.MODEL.SYNC_BN over several ranks: the device-side count check (no host wait)
+            ops.sync_bn_poll()
         return loss
 
     # ---- hipGraph mode --------------------------------------------------------------------------------------------

@@ -225,8 +225,36 @@ SYNC_BN_CALLS = [0]       # BatchNorm layers that exchanged their statistics acr
 
 _SYNC_BN_GROUP = [None]     # the statistics' own communicator (created once, collectively, at the first synchronised layer)
 _SYNC_BN_COUNTS = {}        # (local element count, world) -> element count over all ranks
-_SYNC_BN_USES = {}          # ... -> how often the key was used (periodic re-validation of the cached count)
-_SYNC_BN_CHECK = int(os.environ.get("MRFP_SYNCBN_CHECK_EVERY", "512"))
+_SYNC_BN_FLAG = {}          # device -> int32[1]: number of layers whose all-reduced count differed from the cached one (device side)
+_SYNC_BN_POLL = {}          # device -> (pinned int32[1], event) of the asynchronous read-back in flight
+
+
+def sync_bn_poll(block=False):
+    """Raise if a SYNC_BN layer has seen an all-reduced element count that differs from the one cached for its shape (a rank with a
+    partial last batch).  The comparison runs ON THE DEVICE in every synchronised layer; this function looks at its result without a
+    host synchronisation of its own: it checks the asynchronous read-back started by the previous call if that has landed, and starts
+    the next one (harness.Trainer.step calls it once per step, so a mismatch raises one or two steps after it happened);
+    block=True waits for the flag as it stands now (tests, the end of a run)."""
+    for dev, flag in list(_SYNC_BN_FLAG.items()):
+        pend = _SYNC_BN_POLL.get(dev)
+        if block:
+            bad = int(flag.item())
+            _SYNC_BN_POLL.pop(dev, None)
+        else:
+            bad = 0
+            if pend is not None and pend[1].query():
+                bad = int(pend[0].item())
+                pend = None
+            if pend is None:
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(flag, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                _SYNC_BN_POLL[dev] = (host, ev)
+        if bad:
+            flag.zero_()
+            raise _lib.MrfpHipError("SYNC_BN: the element count over all ranks differed from the cached one in %d layer call(s) -- a rank "
+                                    "ran a batch of another size; uneven per-rank batches are not supported (use a drop_last loader)" % bad)
 
 
 def _sync_bn_group():
@@ -265,17 +293,19 @@ def _allreduce_stats(ws, rows, C, count, group):
     if count:
         # UNEVEN PER-RANK BATCHES ARE NOT SUPPORTED under SYNC_BN: the cached total is keyed by this rank's count alone, so a rank
         # whose batch shrinks while this one's does not (a partial last batch of a non-drop_last loader) would leave it stale.
-        # Every MRFP_SYNCBN_CHECK_EVERY-th use of a key (default 512: one host synchronisation per ~5 steps of the bench network)
-        # the all-reduced count is read back again and compared -- a mismatch raises instead of normalising with the wrong N.
+        # The first use of a key reads the all-reduced count back (one host synchronisation per layer shape, in the first step);
+        # EVERY later use compares the all-reduced count with the cached one on the device and adds a mismatch to a flag that
+        # sync_bn_poll() reads without a host synchronisation of its own (harness.Trainer.step: once per step) -- a step that
+        # normalised with a stale N is reported one or two steps later, every time, not on one use in 512.
         key = (int(count), dist.get_world_size(group))
         total = _SYNC_BN_COUNTS.get(key)
-        uses = _SYNC_BN_USES[key] = _SYNC_BN_USES.get(key, 0) + 1
-        if total is None or (_SYNC_BN_CHECK > 0 and uses % _SYNC_BN_CHECK == 0):
-            now = int(round(tot[2 * C].item()))
-            if total is not None and now != total:
-                raise _lib.MrfpHipError("SYNC_BN: the element count over all ranks changed from %d to %d while this rank's stayed %d "
-                                        "-- uneven per-rank batches are not supported (use a drop_last loader)" % (total, now, count))
-            total = _SYNC_BN_COUNTS[key] = now
+        if total is None:
+            total = _SYNC_BN_COUNTS[key] = int(round(tot[2 * C].item()))
+        else:
+            flag = _SYNC_BN_FLAG.get(ws.device)
+            if flag is None:
+                flag = _SYNC_BN_FLAG[ws.device] = torch.zeros(1, dtype=torch.int32, device=ws.device)
+            flag.add_((tot[2 * C:2 * C + 1] != float(total)).to(torch.int32))
     return torch.stack([hi, lo]).contiguous(), total
 
 
@@ -1285,7 +1315,10 @@ class _AlgebraGraph:
     scheme of torch.cuda.make_graphed_callables, written out because the algebra is a closure inside an autograd Function and its
     running-statistics buffers must survive the warm-up runs).  Same kernels in the same order as the eager path: bit-identical results
     (tests/test_whitening_gpu.py).  A replay overwrites the static tensors the backward graph reads, so a second forward of the same layer
-    before its backward falls back to the eager algebra (`pending`)."""
+    before its backward falls back to the eager algebra: the graph is `busy` while the token of the forward that replayed it is alive
+    and not yet consumed by its backward -- the token lives on that forward's autograd node, so a forward whose backward never comes
+    (an exception, a dropped loss, a statistics-only pass) frees the graph when its node is collected instead of leaving the layer on
+    the eager algebra for the rest of the process."""
 
     def __init__(self, algebra, s, M, params, buffers):
         self.params = tuple(p for p in params if p.requires_grad)
@@ -1314,7 +1347,28 @@ class _AlgebraGraph:
         self.bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.bwd, pool=pool):
             self.grads = torch.autograd.grad((self.Wm, self.shift), self.inputs, (self.dWm, self.dshift), allow_unused=True)
-        self.pending = False
+        self._owner = None          # weakref to the token of the forward whose backward has not replayed `bwd` yet
+
+    @property
+    def busy(self):
+        return self._owner is not None and self._owner() is not None
+
+    def acquire(self):
+        tok = _GraphToken()
+        self._owner = weakref.ref(tok)
+        return tok
+
+    def release(self, tok):
+        if self._owner is not None and self._owner() is tok:
+            self._owner = None
+
+
+class _GraphToken:
+    """Held by the autograd node of the forward that replayed an _AlgebraGraph (weak-referenced by the graph)."""
+    __slots__ = ("__weakref__",)
+
+
+_ALG_GRAPH_CAP = 4           # graphs (each with its private pool) kept per module: one per input shape / mode, least recently used out
 
 
 _ALG_GRAPHS = weakref.WeakKeyDictionary()      # module -> {(shape, mode, parameter / buffer addresses): _AlgebraGraph}
@@ -1333,12 +1387,13 @@ class _GroupWhiten(torch.autograd.Function):
     def forward(ctx, x, algebra, graph, *params):
         x = _chk(x)
         s, M = _gm_call(x, x)
-        g = graph if (graph is not None and not graph.pending) else None
+        g = graph if (graph is not None and not graph.busy) else None
+        ctx.tok = None
         if g is not None:
             g.s.detach().copy_(s)
             g.M.detach().copy_(M)
             g.fwd.replay()
-            g.pending = True
+            ctx.tok = g.acquire()
             s_l, M_l, Wm, shift = g.s, g.M, g.Wm, g.shift
             Wm_c, shift_c = Wm.detach().float().clone(), shift.detach().float().contiguous()     # (Wm_c is saved for backward: its own copy)
         else:
@@ -1365,19 +1420,23 @@ class _GroupWhiten(torch.autograd.Function):
             g.dWm.copy_(dWm)
             g.dshift.copy_(dshift.view_as(g.dshift))
             g.bwd.replay()
-            g.pending = False
             grads = tuple(t.detach().clone() if t is not None else None for t in g.grads)
-            inputs = g.inputs
+            g.release(ctx.tok)
+            ctx.tok = None
+            wrt = g.params
         else:
-            inputs = (s_l, M_l) + tuple(p for p in ctx.params if p.requires_grad)
-            grads = torch.autograd.grad((Wm, shift), inputs, (dWm.to(Wm.dtype), dshift.view_as(shift).to(shift.dtype)),
+            wrt = tuple(p for p in ctx.params if p.requires_grad)
+            grads = torch.autograd.grad((Wm, shift), (s_l, M_l) + wrt, (dWm.to(Wm.dtype), dshift.view_as(shift).to(shift.dtype)),
                                         allow_unused=True)
         ds = grads[0] if grads[0] is not None else torch.zeros_like(s_l)
         dM = grads[1] if grads[1] is not None else torch.zeros_like(M_l)
         sym = (dM + dM.transpose(-1, -2)).float().contiguous()
         dx = _ga_call(dy, Wm_c.transpose(-1, -2).contiguous(), z=x, Vm=sym, shift=ds.float().contiguous())
-        it = iter(grads[2:])
-        return (dx, None, None) + tuple(next(it) if p.requires_grad else None for p in ctx.params)
+        # parameter gradients BY IDENTITY of the tensors they were taken with respect to (a captured graph fixed that set at capture
+        # time; weight / bias and the two blend weights have equal shapes, so a positional hand-out after a requires_grad_ flip
+        # would give one parameter the other's gradient)
+        by_param = {id(p): gp for p, gp in zip(wrt, grads[2:])}
+        return (dx, None, None) + tuple(by_param.get(id(p)) if p.requires_grad else None for p in ctx.params)
 
 
 def group_whiten(x, algebra, params, graph=None):
@@ -1389,16 +1448,34 @@ def group_whiten(x, algebra, params, graph=None):
     if graph is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         owner, key, buffers = graph
         cache = _ALG_GRAPHS.setdefault(owner, {})
-        key = key + tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in buffers)
+        # (the requires_grad flags are part of the key: the captured backward graph differentiates with respect to the parameters
+        #  that required a gradient AT CAPTURE TIME -- freezing or unfreezing one later must not reuse that graph)
+        key = key + tuple(t.data_ptr() for t in params) + tuple(bool(t.requires_grad) for t in params) \
+            + tuple(t.data_ptr() for t in buffers)
         g = cache.get(key)
-        if g is None:
-            # captured HERE, not inside the autograd Function (a capture begun inside Function.forward ends in a segmentation fault in
-            # hipStreamEndCapture on this stack), over well-conditioned stand-in inputs: zero sums, identity covariance
+        if g is not None:
+            cache[key] = cache.pop(key)              # most recently used last
+        elif torch.is_grad_enabled() and not _inside_autograd_engine():
+            # Captured HERE, in the caller's plain Python frame, never from inside the autograd machinery: a capture begun inside
+            # autograd.Function.forward ends in a segmentation fault in hipStreamEndCapture on this stack (a process abort, not an
+            # exception), and a forward issued from inside a backward pass (activation checkpointing, a custom backward that
+            # recomputes) would run this build -- a side-stream warm-up, two captures, a re-entrant autograd.grad -- on the engine's
+            # thread in that same kind of context.  There the layer simply runs the eager algebra (and uses the graph once a plain
+            # forward has built it).  Stand-in inputs: zero sums, identity covariance (well conditioned).
             B, C, H, W = x.shape
             s0 = torch.zeros(B, C, dtype=torch.float32, device=x.device)
             M0 = (torch.eye(16, dtype=torch.float32, device=x.device) * float(H * W)).expand(B, C // 16, 16, 16).contiguous()
             g = cache[key] = _AlgebraGraph(algebra, s0, M0, params, buffers)
+            while len(cache) > _ALG_GRAPH_CAP:       # variable input shapes: a bounded number of graphs / private pools per module
+                cache.pop(next(iter(cache)))
     return _GroupWhiten.apply(x, algebra, g, *params)
+
+
+def _inside_autograd_engine():
+    """True while the autograd engine is executing a graph task on this thread (conv._in_backward, repeated here: ops does not
+    import conv)."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f is not None and f() != -1
 
 
 # ------------------------------------------------------------------------------------------

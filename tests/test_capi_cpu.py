@@ -9,6 +9,8 @@ import torch
 
 from mrfp_amd import _lib, build
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.fixture(scope="module")
 def cdll():
@@ -78,14 +80,24 @@ def test_wgrad_workspace_covers_the_accumulator_stationary_kernels(cdll):
     one.argtypes = [ctypes.c_int64] * 3
     grp.argtypes = [ctypes.c_int64] * 4
 
+    # the grids of the persistent kernels come from ONE constant (csrc/common.hpp: kCUs; conv_common.hpp: kGrid1PerCU / kGrid2PerCU): read
+    # it from the source instead of repeating the numbers here
+    import re
+    src = open(os.path.join(ROOT, "mrfp_amd", "csrc", "common.hpp")).read()
+    cus = int(re.search(r"constexpr int kCUs = (\d+);", src).group(1))
+    cc = open(os.path.join(ROOT, "mrfp_amd", "csrc", "conv_common.hpp")).read()
+    assert "kGrid1PerCU = kCUs;" in cc and "kGrid2PerCU = 2 * kCUs;" in cc
+    for f_, lit in (("conv_wg3.hip", r"\b512\s*/\s*count"), ("conv_wg1.hip", r"\b256\s*/\s*count"), ("conv_c64.hip", r"\?\s*512\s*:\s*256")):
+        assert not re.search(lit, open(os.path.join(ROOT, "mrfp_amd", "csrc", f_)).read()), "a grid literal came back in " + f_
+
     def slots3(N, Q, count):
         ncls = (N // 64) * (Q // 576)
-        a = (512 // count) // ncls
+        a = (2 * cus // count) // ncls
         return a + 2 if a >= 1 else 0
 
     def slots1(N, Q, count):
         ncls = (N // 256) * (Q // 256)
-        a = (256 // count) // ncls
+        a = (cus // count) // ncls
         return a + 2 if a >= 1 else 0
     for M, N, Q, count in [(16 * 384 * 384, 64, 576, 1), (16 * 384 * 384, 128, 576, 1), (16 * 192 * 192, 256, 2304, 1), (16 * 192 * 192, 256, 2880, 1),
                            (36864, 256, 2304, 22), (36864, 512, 4608, 3), (16 * 192 * 192, 64, 576, 3), (16 * 96 * 96, 128, 1152, 3)]:

@@ -335,6 +335,53 @@ def test_sync_batchnorm_two_ranks_equal_one_process_on_the_whole_batch(tmp_path)
     assert rel(local["plain"]["y"], full["plain"]["y"][0:2]) > 1e-3
 
 
+def _worker_syncbn_uneven(rank, world, port, outdir):
+    """a rank whose batch shrinks for one step (a partial last batch) while this one's does not leaves this rank's cached
+    global count stale.  Every synchronised layer compares the all-reduced count with the cached one ON THE DEVICE; sync_bn_poll()
+    reports it (here: blocking) -- on the rank whose cache went stale, every time, not on one use in 512."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from mrfp_amd import _lib, ops
+    _syncbn_run(slice(2 * rank, 2 * rank + 2), True)                 # even step: counts cached (2 images per rank)
+    ops.sync_bn_poll(block=True)                                      # nothing to report
+    _syncbn_run(slice(0, 2) if rank == 0 else slice(2, 3), True)      # rank 1 runs ONE image
+    raised = False
+    try:
+        ops.sync_bn_poll(block=True)
+    except _lib.MrfpHipError as e:
+        raised = "uneven per-rank batches" in str(e)
+    # rank 0's key (2 images) was cached with the even total: stale now -> reported; rank 1's key (1 image) is new -> read back fresh
+    assert raised == (rank == 0), (rank, raised)
+    # the non-blocking form: first call starts the read-back, a later one reports
+    _syncbn_run(slice(0, 2) if rank == 0 else slice(2, 3), True)
+    late = False
+    try:
+        ops.sync_bn_poll()
+        torch.cuda.synchronize()
+        ops.sync_bn_poll()
+    except _lib.MrfpHipError:
+        late = True
+    assert late == (rank == 0), (rank, late)
+    open(os.path.join(outdir, "uneven%d.ok" % rank), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_reports_an_uneven_step_from_the_device_side_check(tmp_path):
+    world, port = 2, 29773
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_syncbn_uneven, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert all(os.path.exists(os.path.join(str(tmp_path), "uneven%d.ok" % r)) for r in range(world))
+
+
 def _worker_syncbn_rccl(outdir):
     """cfg.MODEL.SYNC_BN over RCCL itself (backend "nccl", world size 1 forced with MRFP_FORCE_SYNC=1 -- RCCL refuses two ranks on
     one device): the statistics' own communicator (dist.new_group), its float64 all-reduce on the device, the cached global

@@ -186,6 +186,110 @@ def test_switch_whiten_algebra_as_hipgraphs_is_bit_identical_to_the_eager_algebr
         assert torch.equal(a, b)
 
 
+def _sw_step(sw, x, gy):
+    for p in sw.parameters():
+        p.grad = None
+    xx = x.clone().requires_grad_(True)
+    y = sw(xx)
+    y.backward(gy)
+    return [y.detach().clone(), xx.grad.clone()] + [None if p.grad is None else p.grad.clone() for p in sw.parameters()]
+
+
+def _sw_case(seed=5):
+    from mrfp_amd.network.sync_switchwhiten import SwitchWhiten2d
+    torch.manual_seed(seed)
+    sw = SwitchWhiten2d(64, num_pergroup=16, sw_type=2, T=5).to(DEV).train()
+    with torch.no_grad():
+        sw.weight.uniform_(0.5, 1.5)
+        sw.bias.uniform_(-0.5, 0.5)
+        sw.sw_mean_weight.uniform_(-0.5, 0.5)
+        sw.sw_var_weight.uniform_(-0.5, 0.5)
+    g = torch.Generator().manual_seed(9)
+    xs = [(torch.randn(4, 64, 12, 10, generator=g) * (1.0 + i) + 0.2).to(DEV).contiguous(memory_format=torch.channels_last) for i in range(4)]
+    gys = [torch.randn(4, 64, 12, 10, generator=g).to(DEV).contiguous(memory_format=torch.channels_last) for _ in range(4)]
+    return sw, xs, gys
+
+
+def test_algebra_graph_follows_a_parameter_frozen_after_the_first_capture(monkeypatch):
+    """the captured backward graph differentiates with respect to the parameters that required a gradient at capture
+    time.  Freezing `weight` after the first step (fine-tuning) must not hand `bias` the gradient of `weight` (equal shapes), nor
+    raise; unfreezing again must work too.  Compared against the eager algebra, bit for bit."""
+    res = []
+    for graph in ("1", "0"):
+        monkeypatch.setenv("MRFP_WHITEN_GRAPH", graph)
+        sw, xs, gys = _sw_case()
+        out = _sw_step(sw, xs[0], gys[0])
+        sw.weight.requires_grad_(False)
+        out += [t for t in _sw_step(sw, xs[1], gys[1]) if t is not None]
+        assert sw.weight.grad is None and sw.bias.grad is not None
+        sw.sw_var_weight.requires_grad_(False)
+        sw.weight.requires_grad_(True)
+        out += [t for t in _sw_step(sw, xs[2], gys[2]) if t is not None]
+        assert sw.sw_var_weight.grad is None and sw.weight.grad is not None
+        res.append(out)
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_algebra_graph_is_released_by_a_forward_that_never_gets_its_backward(monkeypatch):
+    """a training forward whose backward never comes (a dropped loss) must not leave the layer on the eager algebra:
+    the graph is busy only while that forward's autograd node is alive.  The per-module cache is bounded."""
+    from mrfp_amd import ops
+    monkeypatch.setenv("MRFP_WHITEN_GRAPH", "1")
+    sw, xs, gys = _sw_case()
+    _sw_step(sw, xs[0], gys[0])
+    (gr,) = ops._ALG_GRAPHS[sw].values()
+    assert not gr.busy
+    y = sw(xs[1].clone().requires_grad_(True))          # forward only
+    assert gr.busy
+    y2 = sw(xs[2].clone().requires_grad_(True))         # second forward while the first is pending: eager algebra, graph untouched
+    assert gr.busy
+    del y, y2                                           # the losses are dropped: nodes collected
+    assert not gr.busy, "a forward without backward must release the graph when its autograd node dies"
+    replays = []
+    orig = gr.fwd.replay
+    gr.fwd.replay = lambda: (replays.append(1), orig())[1]
+    _sw_step(sw, xs[3], gys[3])
+    assert replays == [1], "the next training step runs on the captured graph again"
+    # bounded cache: more shapes than the cap
+    for h in range(6, 6 + ops._ALG_GRAPH_CAP + 2):
+        x = torch.randn(2, 64, h, 8, device=DEV).contiguous(memory_format=torch.channels_last)
+        _sw_step(sw, x, torch.ones_like(x))
+    assert len(ops._ALG_GRAPHS[sw]) <= ops._ALG_GRAPH_CAP
+
+
+def test_algebra_graph_is_not_built_from_inside_a_backward_pass(monkeypatch):
+    """a first forward issued from INSIDE the autograd engine (activation checkpointing recomputes the layer during
+    backward) must not run the graph build there -- a capture begun inside the autograd machinery aborts the process on this
+    stack.  The recomputation runs the eager algebra; results equal the plain eager run."""
+    from torch.utils.checkpoint import checkpoint
+    from mrfp_amd import ops
+    res = []
+    for graph in ("1", "0"):
+        monkeypatch.setenv("MRFP_WHITEN_GRAPH", graph)
+        sw, xs, gys = _sw_case()
+        xx = xs[0].clone().requires_grad_(True)
+        y = checkpoint(sw, xx, use_reentrant=False)     # forward under no_grad-like saving; recomputed in backward
+        y.backward(gys[0])
+        res.append([y.detach().clone(), xx.grad.clone(), sw.weight.grad.clone(), sw.sw_mean_weight.grad.clone()])
+        if graph == "1":
+            built_in_engine = len(ops._ALG_GRAPHS.get(sw, {}))
+            # the plain forward of the checkpoint may have built it (grad mode on, outside the engine); the recomputation must not
+            assert built_in_engine <= 1
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # ... and a layer whose FIRST contact is the recomputation itself (reentrant checkpoint: the first forward runs under no_grad)
+    monkeypatch.setenv("MRFP_WHITEN_GRAPH", "1")
+    sw, xs, gys = _sw_case()
+    xx = xs[0].clone().requires_grad_(True)
+    y = checkpoint(sw, xx, use_reentrant=True)
+    assert len(ops._ALG_GRAPHS.get(sw, {})) == 0
+    y.backward(gys[0])
+    assert len(ops._ALG_GRAPHS.get(sw, {})) == 0, "no graph build on the autograd engine's thread"
+    assert torch.equal(y.detach(), res[1][0]) and torch.equal(xx.grad, res[1][1])
+
+
 def test_group_isqrt_matches_newton_schulz_autograd():
     """mrfp_group_isqrt_{fwd,bwd} against the reference's Newton-Schulz loop differentiated by torch autograd."""
     from mrfp_amd import ops
