@@ -25,13 +25,22 @@
 #include "conv_common.hpp"
 #include <type_traits>
 
+// MRFP_WREG (build switch, default 0; round 6 experiment, profiles/r06_experiments.md): the WEIGHT fragments of the 16-bit ALIGNED
+// kernels go global -> registers (one buffer_load_dwordx4 per 16x32 fragment, issued where the K tile's LDS-DMA is issued) instead of
+// global -> LDS -> registers: the activation tile alone passes through LDS, so the LDS-DMA landing traffic and the ds_read_b128 count
+// of a K tile both drop by BN / (BM + BN) (tools/fill_micro.hip: fragment reads beside the DMA halve the DMA's rate).
+// bit 0: the plain single-buffer loop, bit 1: the row-reuse loop.
+#ifndef MRFP_WREG
+#define MRFP_WREG 0
+#endif
+
 namespace mrfp {
 
 MRFP_STAMP_DECL(g_stamps_igemm)
 int stamps_igemm(unsigned long long* out, int n) { return MRFP_STAMP_READ(g_stamps_igemm, out, n); }
 
 template <typename T, int WM, int WN, bool ALIGNED, bool STRIDED, int TM, int TN, bool RR = false>
-__global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
+__global__ __launch_bounds__(64 * WM * WN, (((RR || ((MRFP_WREG & 1) && ALIGNED && sizeof(T) == 2)) && TM * TN >= 6) ? 2 : 3)) void conv_igemm_kernel(ConvP p) {   // 2nd = waves per SIMD
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int SA = BM * 8 / NT, SB = BN * 8 / NT, RSTEP = NT / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,6 +129,19 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
     }
 
     typedef __attribute__((address_space(3))) void lds_void;
+    constexpr bool M16 = kM16 && sizeof(T) == 2;
+    constexpr bool WREG = (MRFP_WREG & 1) && M16 && ALIGNED && !RR;      // weight fragments through registers (plain loop)
+    const int l15 = lane & 15, lq = lane >> 4;
+    // WREG: byte offset of weight row n = (this wave's column block j) * 16 + l15 in the pack, + this lane quarter's chunk
+    unsigned wq_base[2 * TN];
+    uint4 fbn[2][2 * TN];          // the NEXT K tile's weight fragments [k step][column block], in flight beside its LDS-DMA
+    if constexpr (WREG) {
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) {
+            const int n = n0 + wn * 32 * TN + j * 16 + l15;
+            wq_base[j] = n < p.N ? (unsigned)n * (unsigned)p.kchunks * 16u + (unsigned)lq * 16u : kOOB;
+        }
+    }
     auto load_tile = [&](int kt) {
         const int dh = tr * p.dil, dw = ts * p.dil;
         const int cc = ALIGNED ? tc * 8 + chunk : tc;
@@ -145,10 +167,20 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
         const unsigned qoff = !qok ? kOOB
                               : ALIGNED ? (unsigned)((tr * p.S + ts) * p.cpr + tc * 8 + chunk) * 16u
                                         : (unsigned)(kt * 8 + chunk) * 16u;
+        if constexpr (WREG) {
+            // (ALIGNED) the K tile's 8 chunks of weight row n start at chunk (tap * cpr + tc * 8); lane quarter lq takes chunk 4 kk + lq
+            const unsigned t0 = (unsigned)((tr * p.S + ts) * p.cpr + tc * 8) * 16u;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 2 * TN; ++j)
+                    fbn[kk][j] = bload(wr, wq_base[j] >= kOOB ? kOOB : wq_base[j] + t0 + (unsigned)(kk * 64));
+        } else {
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const unsigned voff = (b_base[i] >= kOOB || !qok) ? kOOB : b_base[i] + qoff;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(sB0 + (wrow + i * RSTEP) * 128), 16, (int)voff, 0, 0, 0);
+        }
         }
         // advance to the next K tile.  ALIGNED: channel chunk OUTER, filter tap INNER -- the R*S taps of one 64-channel
         // slab re-read (shifted) the same input pixels back to back, so 8 of 9 reads of a 3x3 convolution are served
@@ -170,7 +202,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
         }
     };
 
-    constexpr bool M16 = kM16 && sizeof(T) == 2;
     f32x16 acc[TM][TN];
     f32x4 acc16[2 * TM][2 * TN];       // M16: 16x16 blocks, D[row = 4*(lane>>4) + e][col = lane&15]
 #pragma unroll
@@ -188,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
 
     const int nkt = classed ? ((p.R - tr0 + 1) >> 1) * ((p.S - ts0 + 1) >> 1) * (p.cpr >> 3) : (p.kchunks + 7) >> 3;
     const int lr = lane & 31, lh = lane >> 5;
-    const int l15 = lane & 15, lq = lane >> 4;
+    uint4 fbc[2][2 * TN];          // WREG: the CURRENT K tile's weight fragments
     auto compute = [&](int kk0 = 0, int kk1 = 2) {
         const char* a = sA0;
         const char* b = sB0;
@@ -200,7 +231,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
 #pragma unroll
                 for (int i = 0; i < 2 * TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(a + lds_off(wm * 32 * TM + i * 16 + l15, ch));
 #pragma unroll
-                for (int j = 0; j < 2 * TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 32 * TN + j * 16 + l15, ch));
+                for (int j = 0; j < 2 * TN; ++j) {
+                    if constexpr (WREG) fb[j] = fbc[kk][j];
+                    else fb[j] = *reinterpret_cast<const uint4*>(b + lds_off(wn * 32 * TN + j * 16 + l15, ch));
+                }
 #pragma unroll
                 for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
@@ -345,6 +379,13 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
                 // the barrier (`s_waitcnt vmcnt(5); s_barrier; s_waitcnt vmcnt(0); ds_read` in the ISA) -- a wave would pass the
                 // barrier with its pieces still in flight and the others would read stale LDS
                 dma_wait<0>();
+                if constexpr (WREG) {
+                    // (vmcnt(0) above covers the register loads too) next -> current: the loads of tile kt + 1 below get fresh registers
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int j = 0; j < 2 * TN; ++j) { fbc[kk][j] = fbn[kk][j]; settle(fbc[kk][j]); }
+                }
                 __syncthreads();      // barrier: tile kt has landed everywhere
                 if constexpr (HOLD == 1) compute(0, 1);
 #pragma unroll
@@ -353,7 +394,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((RR && TM * TN >= 6) ? 2 : 3)) void 
 #pragma unroll
                     for (int i = 0; i < 2 * TM; ++i) fa[h][i] = *reinterpret_cast<const uint4*>(sA0 + lds_off(wm * 32 * TM + i * 16 + l15, ch));
 #pragma unroll
-                    for (int j = 0; j < 2 * TN; ++j) fb[h][j] = *reinterpret_cast<const uint4*>(sB0 + lds_off(wn * 32 * TN + j * 16 + l15, ch));
+                    for (int j = 0; j < 2 * TN; ++j) {
+                        if constexpr (WREG) fb[h][j] = fbc[2 - HOLD + h][j];
+                        else fb[h][j] = *reinterpret_cast<const uint4*>(sB0 + lds_off(wn * 32 * TN + j * 16 + l15, ch));
+                    }
                 }
                 __syncthreads();      // lgkmcnt(0) + barrier: every wave holds its last fragments, the buffer is free
                 if (kt + 1 < nkt) load_tile(kt + 1);

@@ -1445,7 +1445,9 @@ def group_whiten(x, algebra, params, graph=None):
     everything the algebra bakes in besides `params` -- shape, mode --, the buffers it updates in place) lets the algebra run as two
     captured hipGraphs (_AlgebraGraph); None: eager."""
     g = None
-    if graph is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+    # (no graph under saved-tensor hooks -- torch.utils.checkpoint(use_reentrant=False), activation offloading: they compare / replay
+    #  what the forward SAVES, and the replayed algebra saves different tensors than the eager one the recomputation may fall back to)
+    if graph is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing() and not _saved_tensor_hooks_active():
         owner, key, buffers = graph
         cache = _ALG_GRAPHS.setdefault(owner, {})
         # (the requires_grad flags are part of the key: the captured backward graph differentiates with respect to the parameters
@@ -1469,6 +1471,14 @@ def group_whiten(x, algebra, params, graph=None):
             while len(cache) > _ALG_GRAPH_CAP:       # variable input shapes: a bounded number of graphs / private pools per module
                 cache.pop(next(iter(cache)))
     return _GroupWhiten.apply(x, algebra, g, *params)
+
+
+def _saved_tensor_hooks_active():
+    f = getattr(torch._C._autograd, "_top_saved_tensors_default_hooks", None)
+    try:
+        return f is not None and f(False) is not None
+    except Exception:       # an interpreter without the query: assume hooks may be active (eager algebra, always correct)
+        return True
 
 
 def _inside_autograd_engine():

@@ -12,7 +12,9 @@ shapes = {"big3x3": (16, 256, 192, 192, 256, 3, 1, 1, 1), "l3_3x3": (16, 256, 48
           "exp1x1": (16, 64, 192, 192, 256, 1, 1, 0, 1), "hrfp128": (16, 256, 384, 384, 128, 3, 1, 1, 1), "n64a": (16, 128, 384, 384, 64, 3, 1, 1, 1), "n64b": (16, 64, 192, 192, 64, 3, 1, 1, 1), "l3_exp": (16, 256, 48, 48, 1024, 1, 1, 0, 1), "l2_exp": (16, 128, 96, 96, 512, 1, 1, 0, 1),
           "dec304": (16, 304, 192, 192, 256, 3, 1, 1, 1), "l4_3x3": (16, 512, 48, 48, 512, 3, 1, 2, 2),
           "l4_red": (16, 2048, 48, 48, 512, 1, 1, 0, 1), "l4_exp": (16, 512, 48, 48, 2048, 1, 1, 0, 1), "l2_3x3": (16, 128, 96, 96, 128, 3, 1, 1, 1),
-          "hrfp64_128": (16, 64, 384, 384, 128, 3, 1, 1, 1), "hrfp64_64": (16, 64, 384, 384, 64, 3, 1, 1, 1), "head32": (16, 32, 384, 384, 256, 1, 1, 0, 1)}
+          "hrfp64_128": (16, 64, 384, 384, 128, 3, 1, 1, 1), "hrfp64_64": (16, 64, 384, 384, 64, 3, 1, 1, 1), "head32": (16, 32, 384, 384, 256, 1, 1, 0, 1),
+          "aspp12": (16, 2048, 48, 48, 256, 3, 1, 12, 12), "dec256": (16, 256, 192, 192, 256, 3, 1, 1, 1), "hrfp332": (16, 128, 332, 332, 256, 3, 1, 2, 2),
+          "l3_down": (16, 512, 96, 96, 1024, 1, 2, 0, 1)}
 B, C, H, W, N, k, st, pad, dil = shapes[which]
 x = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
 w = (torch.randn(N, C, k, k, device="cuda") * 0.05).requires_grad_(True)
