@@ -76,6 +76,41 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
     __syncthreads();
     T* wf = reinterpret_cast<T*>(jb.wf);
     T* wd = reinterpret_cast<T*>(jb.wd);
+    if constexpr (sizeof(T) == 2) {
+        // 16-bit packs with whole 16-byte chunks on both axes (every pack of the networks here): a thread converts EIGHT values and
+        // stores one chunk -- the element-wise loops below issue eight 2-byte stores for it (round 6: 227 -> see profiles/r06_experiments.md
+        // us per step for the 124 + 8 packs of the bench network).  Same values, same rounding: the packs are bit-identical.
+        if ((Cpad & 7) == 0 && (Npad & 7) == 0) {
+            const int cg = bc >> 3;                 // chunks of 8 input channels per brick: 1 (3x3) or 8 (pointwise)
+            for (int e = t; e < kBrickN * RS * cg; e += 256) {          // forward pack wf[n][rs][c .. c+7]
+                const int g = e % cg, rest = e / cg;
+                const int rs = rest % RS, nn = rest / RS;
+                const int n = n0 + nn, c = c0 + g * 8;
+                if (n < Npad && c < Cpad) {
+                    T v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = from_f<T>(brick[nn][(g * 8 + u) * RS + rs]);
+                    uint4 q;
+                    __builtin_memcpy(&q, v, 16);
+                    *reinterpret_cast<uint4*>(wf + ((size_t)n * RS + rs) * Cpad + c) = q;
+                }
+            }
+            for (int e = t; e < bc * RS * (kBrickN / 8); e += 256) {     // dgrad pack wd[c][flipped rs][n .. n+7]
+                const int ng = e % (kBrickN / 8), rest = e / (kBrickN / 8);
+                const int rs = rest % RS, cc = rest / RS;
+                const int n = n0 + ng * 8, c = c0 + cc;
+                if (n < Npad && c < C) {
+                    T v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = from_f<T>(brick[ng * 8 + u][cc * RS + rs]);
+                    uint4 q;
+                    __builtin_memcpy(&q, v, 16);
+                    *reinterpret_cast<uint4*>(wd + ((size_t)c * RS + (RS - 1 - rs)) * Npad + n) = q;
+                }
+            }
+            return;
+        }
+    }
     // forward pack: wf[n][rs][c]  (c fastest over bc consecutive threads)
     for (int e = t; e < kBrickN * run; e += 256) {
         const int cc = e % bc, rest = e / bc;

@@ -707,3 +707,33 @@ def test_long_k_pointwise_kernel(case):
     F.conv2d(xc, wc).backward(gy)
     yd.backward(gy.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
     assert relerr(xd.grad, xc.grad) < 1e-2 and relerr(wd.grad, wc.grad) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_batched_weight_pack_equals_the_per_layer_pack(dtype):
+    """mrfp_pack_weights_batched (ONE launch after the optimizer step for every pack of the model; round 6: 16-byte stores for the
+    16-bit packs) against mrfp_pack_weight (the per-layer kernel) -- forward pack [N][r][s][C] and flipped dgrad pack [C][r][s][N] bit
+    for bit, pad rows / pad channels included: 3x3 and 1x1 filters, N = 19 -> 32 (final2), C = 3 -> 8 (network input), 304 -> 320
+    (decoder concatenation), a 2x2 filter, dimensions that are not multiples of the 64 x 8 brick."""
+    from mrfp_amd import conv
+    epc = 4 if dtype == torch.float32 else 8
+    g = torch.Generator().manual_seed(3)
+    cases = [(256, 256, 3, 3, 256, 256), (1024, 256, 1, 1, 1024, 256), (19, 256, 1, 1, 32, 256), (64, 3, 3, 3, 64, 8),
+             (256, 304, 3, 3, 256, 320), (72, 40, 2, 2, 72, 40), (100, 24, 3, 3, 104, 24), (48, 1280, 1, 1, 48, 1280)]
+    todo, ref = [], []
+    for (N, C, R, S, Nphys, Cphys) in cases:
+        Nphys, Cphys = (Nphys + epc - 1) // epc * epc, (Cphys + epc - 1) // epc * epc
+        w = torch.randn(N, C, R, S, generator=g).to(DEV).requires_grad_(True)
+        pk = conv.get_pack(w, None, dtype, Cphys, Nphys)          # per-layer kernel
+        ref.append((pk.wf.clone(), pk.wd.clone()))
+        pk.wf.fill_(7.0)
+        if Cphys == C:
+            pk.wd.fill_(7.0)                                      # (pad input-channel rows of wd are zero by allocation and never written)
+        else:
+            pk.wd.view(Cphys, -1)[:C].fill_(7.0)
+        todo.append(((dtype, Cphys, Nphys, w.data_ptr(), 0), pk, w))
+    conv._batched_repack(todo, "test_pack_%s" % dtype)
+    torch.cuda.synchronize()
+    for (case, (_, pk, _), (wf, wd)) in zip(cases, todo, ref):
+        assert torch.equal(pk.wf, wf), ("wf", case)
+        assert torch.equal(pk.wd, wd), ("wd", case)
