@@ -296,7 +296,9 @@ int mrfp_conv_fwd_gated(const void* x, const void* wpack, const float* bias, voi
 /* Diagnostic (no reference counterpart): in a library built with -DMRFP_CLOCK_STAMP=1 (tools/clock_stamp.py; never the product
  * build, where this returns -1) every convolution workgroup records d(s_memtime) and d(s_memrealtime) around its main loop; out
  * receives n pairs {shader cycles, 100 MHz ticks} of the LAST launch of `family` (0: conv_igemm, 1: pointwise, 2: wgrad).
- * In-kernel clock = cycles / ticks x 100 MHz (MI355X_MICROARCH.md, DVFS give-back). */
+ * In-kernel clock = cycles / ticks x 100 MHz (MI355X_MICROARCH.md, DVFS give-back).
+ * family 3 (round 6, tools/phase_stamp.py): n pairs {cycles, samples}, eight per (workgroup, wave 0 / wave 4) of the two-group long-K
+ * pointwise kernel -- the cycles that wave spent in each phase of its K loop (csrc/conv_pwk.hip: PhaseClock). */
 int mrfp_debug_clock_stamps(int family, uint64_t* out, int64_t n);
 int64_t mrfp_conv_wgrad_ws_bytes(int64_t M, int64_t N, int64_t Q);
 int mrfp_conv_wgrad(const void* x, const void* dy, float* dw, void* ws, int dtype,

@@ -61,6 +61,7 @@ struct ClockStamp {
 int stamps_igemm(unsigned long long* out, int n);     // conv_igemm.hip
 int stamps_pw(unsigned long long* out, int n);        // conv_pw.hip
 int stamps_wgrad(unsigned long long* out, int n);     // conv_wgrad.hip
+int stamps_pwk(unsigned long long* out, int n);       // conv_pwk.hip: per-phase cycle sums of the two-group long-K pointwise kernel
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

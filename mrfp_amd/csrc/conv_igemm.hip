@@ -928,14 +928,16 @@ static int conv_fwd_impl(const void* x, const void* wpack, const float* bias, vo
     return 0;
 }
 
-/* diagnostic: the clock stamps of the last launch of a kernel family (0: conv_igemm, 1: pointwise, 2: wgrad) -- only in a
- * library built with -DMRFP_CLOCK_STAMP=1 (tools/clock_stamp.py); the product build returns -1 */
+/* diagnostic: the clock stamps of the last launch of a kernel family (0: conv_igemm, 1: pointwise, 2: wgrad; 3: the per-phase cycle sums
+ * of the two-group long-K pointwise kernel, conv_pwk.hip / tools/phase_stamp.py) -- only in a library built with -DMRFP_CLOCK_STAMP=1
+ * (tools/clock_stamp.py); the product build returns -1 */
 int mrfp_debug_clock_stamps(int family, uint64_t* out, int64_t n) {
     MRFP_CHECK(MRFP_CLOCK_STAMP != 0, "clock stamps: not a diagnostic build (-DMRFP_CLOCK_STAMP=1)");
-    MRFP_CHECK(out && n > 0 && n <= kStampSlots && family >= 0 && family <= 2, "clock stamps: bad arguments");
+    MRFP_CHECK(out && n > 0 && n <= kStampSlots && family >= 0 && family <= 3, "clock stamps: bad arguments");
     (void)hipDeviceSynchronize();
     const int rc = family == 0 ? stamps_igemm((unsigned long long*)out, (int)n)
-                   : family == 1 ? stamps_pw((unsigned long long*)out, (int)n) : stamps_wgrad((unsigned long long*)out, (int)n);
+                   : family == 1 ? stamps_pw((unsigned long long*)out, (int)n)
+                   : family == 2 ? stamps_wgrad((unsigned long long*)out, (int)n) : stamps_pwk((unsigned long long*)out, (int)n);
     MRFP_CHECK(rc == 0, "clock stamps: read-back failed");
     return 0;
 }
