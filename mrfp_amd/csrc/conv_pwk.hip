@@ -2,18 +2,15 @@
 
 namespace mrfp {
 
-// MRFP_PWK2_DEFER (build switch, default 1): the two-group kernel finishes a tile (exchange of the K groups' partial sums, statistics,
-// convert, store) behind the NEXT tile's first barrier instead of in place; 0 = the in-place form of round 5 (A/B runs; the test that both
-// give the same bits builds it as a variant library).
-#ifndef MRFP_PWK2_DEFER
-#define MRFP_PWK2_DEFER 1
-#endif
-
 // Phase clock of the two-group kernel (DIAGNOSTIC build only, -DMRFP_CLOCK_STAMP=1, tools/phase_stamp.py; in the product build every PH_*
 // macro is empty and no stamp executes): wave 0 and wave 4 of a workgroup add up the shader cycles (s_memtime) they spend in each phase of
 // the K loop and write {cycles, samples} per phase to a buffer of their own that nothing else reads.  Phases: 0 prologue (first transfers
 // issued, this wave's weights in registers), 1 wait + barrier at the top of a step, 2 issuing the step's four transfers, 3 fragment reads +
 // multiplies, 4 exchange / statistics / stores of a tile, 5 the whole kernel, 6 the whole kernel in 100 MHz ticks (s_memrealtime).
+// What it showed (profiles/r06_experiments.md 6): 8.4 - 9.2 of a workgroup's 23.5 - 25 us pass before all its weights are in registers
+// (every CU starts 96 KB of cold X transfers and 256 KB of weight loads at once: the start-up burst of the memory system, not a
+// bandwidth), the rest streams X at what HBM gives; finishing a tile behind the next barrier and starting on the first weight quarter --
+// both built, both bit-identical -- moved time between the phases and left the sum where it was (tools/experiments/conv_pwk_*.patch).
 #if MRFP_CLOCK_STAMP
 __device__ unsigned long long g_phase_pwk[kStampSlots][2];
 int stamps_pwk(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_pwk), (size_t)n * 16) == hipSuccess ? 0 : -1; }
@@ -345,59 +342,6 @@ __global__ __launch_bounds__(512, 2) void conv1x1_longk2_kernel(PkP p) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) { cs[u] = 0.f; cq[u] = 0.f; }
 
-    // DEFERRED EXCHANGE (round 6; tools/phase_stamp.py: the exchange + convert + store of a tile took group 0 0.56 us with the matrix
-    // pipe idle on every SIMD -- 5.1 of the kernel's 23.5 us).  Group 1 leaves its partial sums of tile t in the exchange buffer right
-    // after its last multiply; group 0 keeps its own sums of tile t in a second accumulator set and finishes the tile behind the barrier
-    // at the top of tile t + 1 -- while group 1, its partner on every SIMD, already multiplies tile t + 1.  One exchange buffer suffices:
-    // group 0 has read tile t's partial sums before the barrier of step 1 of tile t + 1, group 1 writes tile t + 1's after it.
-    // Same additions in the same order: outputs and statistics are bit-identical to the in-place form.
-    f32x4 accp[2][2];
-    uint4 avp[2];
-    unsigned amp[2] = {0xffu, 0xffu};
-    f32x4* const ex = reinterpret_cast<f32x4*>(exch) + (wq * 4) * 64 + lane;
-    auto finish_tile = [&](int tile) {           // group 0: tile's sums = accp + group 1's partial sums -> (statistics) -> store
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 o = ex[(rb * 2 + j) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) accp[rb][j][e] += o[e];
-            }
-            const int m = tile * kPk2Rows + rb * 16 + l15;
-            const bool ok = m < p.M && nl < p.N;
-            if constexpr (STATS) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    cs[u] += accp[rb][0][u];
-                    cs[4 + u] += accp[rb][1][u];
-                    cq[u] = __builtin_fmaf(accp[rb][0][u], accp[rb][0][u], cq[u]);
-                    cq[4 + u] = __builtin_fmaf(accp[rb][1][u], accp[rb][1][u], cq[4 + u]);
-                }
-            }
-            uint4 v;
-            if constexpr (ADD) {
-                const uint4 gt = gate_chunk16(avp[rb], amp[rb]);
-                float a[8];
-                unpack2<T>(gt.x, a[0], a[1]);
-                unpack2<T>(gt.y, a[2], a[3]);
-                unpack2<T>(gt.z, a[4], a[5]);
-                unpack2<T>(gt.w, a[6], a[7]);
-                v.x = pack2<T>(accp[rb][0][0] + a[0], accp[rb][0][1] + a[1]);
-                v.y = pack2<T>(accp[rb][0][2] + a[2], accp[rb][0][3] + a[3]);
-                v.z = pack2<T>(accp[rb][1][0] + a[4], accp[rb][1][1] + a[5]);
-                v.w = pack2<T>(accp[rb][1][2] + a[6], accp[rb][1][3] + a[7]);
-            } else {
-                v.x = pack2<T>(accp[rb][0][0], accp[rb][0][1]);
-                v.y = pack2<T>(accp[rb][0][2], accp[rb][0][3]);
-                v.z = pack2<T>(accp[rb][1][0], accp[rb][1][1]);
-                v.w = pack2<T>(accp[rb][1][2], accp[rb][1][3]);
-            }
-            u32x4 dv;
-            dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
-            __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)(ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB), 0, 0);
-        }
-    };
     int h = 0;
     for (int tile = t0; tile < t1; ++tile) {
         f32x4 acc[2][2];
@@ -407,8 +351,6 @@ __global__ __launch_bounds__(512, 2) void conv1x1_longk2_kernel(PkP p) {
         for (int sst = 0; sst < 2; ++sst, ++h) {
             if (h + NST - 1 <= total) dma_wait<(NST - 2) * NP>();
             else dma_wait<0>();
-            // (group 1's partial sums of the previous tile -- LDS stores -- are complete before the barrier that lets group 0 read them)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             PH_LAP(1);
             if (h + NST - 1 < total) issue(h + NST - 1);
@@ -423,10 +365,6 @@ __global__ __launch_bounds__(512, 2) void conv1x1_longk2_kernel(PkP p) {
                         am[rb] = (p.addend_mask && ok) ? p.addend_mask[((size_t)m * p.ldy + nl) >> 3] : 0xffu;
                     }
                 }
-            }
-            if (MRFP_PWK2_DEFER && sst == 0 && grp == 0 && tile > t0) {
-                finish_tile(tile - 1);
-                PH_LAP(4);
             }
             const char* st = smem + (h % NST) * PAIR + grp * QTR;
             uint4 fx[2][2];
@@ -455,32 +393,60 @@ __global__ __launch_bounds__(512, 2) void conv1x1_longk2_kernel(PkP p) {
             }
             PH_LAP(3);
         }
-        // ---- group 1 leaves its partial sums (lane-matched 16-byte slots); group 0 keeps its own: the tile is finished behind the next barrier
+        // ---- group 1 hands its partial sums over (lane-matched 16-byte slots), group 0 adds them and stores ----------------------
+        f32x4* ex = reinterpret_cast<f32x4*>(exch) + (wq * 4) * 64 + lane;
         if (grp == 1) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) ex[(rb * 2 + j) * 64] = acc[rb][j];
-        } else {
+        }
+        // (NOT __syncthreads(): its fence would also drain the vector-memory counter -- the three pairs of transfers in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 0) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accp[rb][j] = acc[rb][j];
-                if constexpr (ADD) { avp[rb] = av[rb]; amp[rb] = am[rb]; }
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 o = ex[(rb * 2 + j) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[rb][j][e] += o[e];
+                }
+                const int m = tile * kPk2Rows + rb * 16 + l15;
+                const bool ok = m < p.M && nl < p.N;
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cs[u] += acc[rb][0][u];
+                        cs[4 + u] += acc[rb][1][u];
+                        cq[u] = __builtin_fmaf(acc[rb][0][u], acc[rb][0][u], cq[u]);
+                        cq[4 + u] = __builtin_fmaf(acc[rb][1][u], acc[rb][1][u], cq[4 + u]);
+                    }
+                }
+                uint4 v;
+                if constexpr (ADD) {
+                    const uint4 gt = gate_chunk16(av[rb], am[rb]);
+                    float a[8];
+                    unpack2<T>(gt.x, a[0], a[1]);
+                    unpack2<T>(gt.y, a[2], a[3]);
+                    unpack2<T>(gt.z, a[4], a[5]);
+                    unpack2<T>(gt.w, a[6], a[7]);
+                    v.x = pack2<T>(acc[rb][0][0] + a[0], acc[rb][0][1] + a[1]);
+                    v.y = pack2<T>(acc[rb][0][2] + a[2], acc[rb][0][3] + a[3]);
+                    v.z = pack2<T>(acc[rb][1][0] + a[4], acc[rb][1][1] + a[5]);
+                    v.w = pack2<T>(acc[rb][1][2] + a[6], acc[rb][1][3] + a[7]);
+                } else {
+                    v.x = pack2<T>(acc[rb][0][0], acc[rb][0][1]);
+                    v.y = pack2<T>(acc[rb][0][2], acc[rb][0][3]);
+                    v.z = pack2<T>(acc[rb][1][0], acc[rb][1][1]);
+                    v.w = pack2<T>(acc[rb][1][2], acc[rb][1][3]);
+                }
+                u32x4 dv;
+                dv.x = v.x; dv.y = v.y; dv.z = v.z; dv.w = v.w;
+                __builtin_amdgcn_raw_buffer_store_b128(dv, yr, (int)(ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nl) * 2u : kOOB), 0, 0);
             }
         }
-        if (!MRFP_PWK2_DEFER) {                  // the in-place form (A/B runs, the equality test): exchange, barrier, finish, per tile
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (grp == 0) finish_tile(tile);
-        }
-        PH_LAP(4);
-    }
-    if (MRFP_PWK2_DEFER) {
-        // the last tile.  (NOT __syncthreads(): its fence would also drain the vector-memory counter -- the stores of the earlier tiles)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (grp == 0) finish_tile(t1 - 1);
         PH_LAP(4);
     }
     PH_FLUSH(wave);

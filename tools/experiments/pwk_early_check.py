@@ -1,6 +1,7 @@
-"""The two-group long-K pointwise kernel with the deferred exchange (default build) against the in-place form (-DMRFP_PWK2_DEFER=0 variant
+"""The two-group long-K pointwise kernel with the early start on the first weight quarter (default build) against the round-5 form (-DMRFP_PWK2_EARLY=0 variant
 library): plain, fused statistics, addend, gated addend -- output (and statistics rows) must be EQUAL bit for bit; several M (whole ranges,
-ragged tail, one tile per workgroup), repeated launches.   python tools/experiments/pwk_defer_check.py   (builds the variant itself)"""
+ragged tail, one tile per workgroup), repeated launches.  (The switch lives in tools/experiments/conv_pwk_early.patch -- apply it first; the same
+script checked conv_pwk_defer.patch with -DMRFP_PWK2_DEFER=0.  Both: 40 of 40 hashes equal, gpurun_out/r6_pwk_*_check.txt.)   python tools/experiments/pwk_early_check.py   (builds the variant itself)"""
 import hashlib
 import os
 import subprocess
@@ -52,11 +53,11 @@ if __name__ == "__main__":
         child()
         sys.exit(0)
     from mrfp_amd import build
-    lib = build.build_variant("nodefer", ("conv_pwk",), ["-DMRFP_PWK2_DEFER=0"])
+    lib = build.build_variant("noearly", ("conv_pwk",), ["-DMRFP_PWK2_EARLY=0"])
     res = []
     for env in ({}, {"MRFP_HIP_LIB": lib}):
         r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=dict(os.environ, **env))
-        print(("default build" if not env else "in-place build"), "rc", r.returncode)
+        print(("default build" if not env else "round-5 form"), "rc", r.returncode)
         print("\n".join(l for l in r.stdout.splitlines() if l.startswith("shape")))
         if r.returncode:
             print(r.stderr[-1500:])
